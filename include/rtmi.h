@@ -1,0 +1,141 @@
+/* rtmi.h — C ABI of the MI355X path-tracing core (librtmi.so).
+ *
+ * Drop-in boundary for rust_raytrace's `RayCaster` plug-in
+ * (raytrace_lib/src/raytrace.rs:1128-1165).  A Rust `impl RayCaster for
+ * HipRayCaster` flattens `Scene` once, calls rtmi_scene_create(), then
+ * rtmi_render() from walk_rays_internal(); see INTEGRATION.md for the shim.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  Every function
+ * returns RTMI_OK (0) or an error code; the message for the calling thread is
+ * available from rtmi_last_error().  No C++ exception crosses this boundary.
+ * All functions are callable from any host thread (the reference enters its
+ * caster from a scoped worker thread, raytrace.rs:1141-1146); one in-flight
+ * render per scene handle.
+ */
+#ifndef RTMI_H
+#define RTMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    RTMI_OK = 0,
+    RTMI_ERR_INVALID = 1,      /* bad argument / malformed scene            */
+    RTMI_ERR_NO_DEVICE = 2,    /* no HIP device / HIP runtime failure       */
+    RTMI_ERR_UNSUPPORTED = 3,  /* valid input outside what the kernels take */
+    RTMI_ERR_OOM = 4
+};
+
+/* SurfaceKind (raytrace.rs:303-308) */
+enum { RTMI_SOLID = 0, RTMI_MATTE = 1, RTMI_REFLECTIVE = 2 };
+
+/* One `Triangle` (raytrace.rs:326-337) reduced to the fields the hot path
+ * reads (intersects/normal/getsurface, raytrace.rs:399-461).  Lane 3 of every
+ * Vec3 is +0 for records produced by make_triangle (raytrace.rs:340-383) and
+ * is not transported. */
+typedef struct rtmi_triangle {
+    float incenter[3];
+    float norm[3];
+    float bounding_r2;
+    float sides[3][3];
+    float side_lens[3];
+    float edge_thickness;
+    uint32_t surface_kind; /* RTMI_SOLID / RTMI_MATTE / RTMI_REFLECTIVE */
+    float color[3];
+    float alpha;      /* Matte, Reflective */
+    float scattering; /* Reflective */
+} rtmi_triangle_t;
+
+/* One `BoundingBox` (raytrace.rs:618-623), flattened.  Inner box: its children
+ * are boxes[first .. first+count) in the order of `BBSubobj::Boxes`.  Leaf:
+ * its triangle indices are tri_refs[first .. first+count) in the order of
+ * `BBSubobj::Tris`.  boxes[0] is the root (`Scene.boxes`). */
+typedef struct rtmi_box {
+    float orig[3];
+    float len2; /* half edge length */
+    uint32_t first;
+    uint32_t count;
+    uint32_t is_leaf;
+    uint32_t depth;
+} rtmi_box_t;
+
+/* `Viewport` (raytrace.rs:1305-1318).  orig/cam/vu/vv are private in the
+ * reference; the shim recomputes them with create_viewport's formula
+ * (raytrace.rs:1343-1370) or the host crate makes them `pub`. */
+typedef struct rtmi_viewport {
+    uint32_t width, height;
+    float orig[3], cam[3], vu[3], vv[3];
+    uint32_t maxdepth;
+    uint32_t samples_per_pixel;
+} rtmi_viewport_t;
+
+/* Work counters of one render/trace call.  `rays` is the reference's "Rays"
+ * statistic: project_ray calls with depth > 0 (raytrace.rs:1278). */
+typedef struct rtmi_stats {
+    uint64_t rays;
+    uint64_t box_tests, tri_tests, full_tests, nodes, leaves; /* filled only when counting is enabled */
+    double kernel_ms;  /* device time of the render kernels (HIP events)   */
+    double trace_ms;   /* of which: the closest-hit kernel                  */
+    uint32_t trace_launches;
+    uint32_t reserved;
+} rtmi_stats_t;
+
+typedef struct rtmi_scene rtmi_scene_t;
+
+/* Number of visible HIP devices (0 when none); never fails. */
+int rtmi_device_count(void);
+
+/* Upload a scene to `device` and keep it resident until rtmi_scene_destroy().
+ * tris[0] is the never-rendered sentinel (raytrace.rs:791, :849); a hit index
+ * of 0 means "miss".  Replaces the per-batch cudaMalloc/cudaMemcpy of
+ * exec_cuda_raytrace (cuda_raytrace_lib/src/cuda_rt.cu:381-425). */
+int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris,
+                      const rtmi_box_t* boxes, uint64_t nboxes,
+                      const uint32_t* tri_refs, uint64_t nrefs,
+                      int device, rtmi_scene_t** out);
+int rtmi_scene_destroy(rtmi_scene_t* scene);
+
+/* Option switches (all default 0): */
+enum {
+    RTMI_OPT_COUNTERS = 1u << 0, /* fill box/tri/node counters in rtmi_stats_t (slower) */
+    RTMI_OPT_GENERIC = 1u << 1   /* force the generic-tree traversal kernel              */
+};
+int rtmi_scene_set_options(rtmi_scene_t* scene, uint32_t options);
+
+/* Render image rows [row0, row0+nrows) of the viewport into `out`
+ * (nrows*width*4 floats, row-major, RGB + a zero lane == `[Color]`,
+ * raytrace.rs:1183, :1426).  Same pixel values for any row partition.
+ * Replaces RayCaster::walk_rays_internal (raytrace.rs:1129-1131, :1175-1196)
+ * with the RNG of the build (seed) injected at rand::random's call sites.
+ * rtmi_render writes host memory; rtmi_render_device writes device memory on
+ * `hip_stream` (a hipStream_t, or NULL for the default stream) and returns
+ * after the work is enqueued and the counters are read back. */
+int rtmi_render(rtmi_scene_t* scene, const rtmi_viewport_t* vp, uint64_t seed,
+                uint32_t row0, uint32_t nrows, float* out_host, rtmi_stats_t* stats);
+int rtmi_render_device(rtmi_scene_t* scene, const rtmi_viewport_t* vp, uint64_t seed,
+                       uint32_t row0, uint32_t nrows, void* out_device, void* hip_stream,
+                       rtmi_stats_t* stats);
+
+/* Closest hit for n explicit rays: orig (x,y,z,lane3) and unit dir
+ * (x,y,z,lane3) as `make_ray` stores them (raytrace.rs:201-210).  Outputs per
+ * ray: triangle index (0 = miss), hit time, face (0 front, 1 back, 2 edge
+ * front, 3 edge back).  Same function as the reference's native entry point
+ * exec_cuda_raytrace (cuda_raytrace_lib/src/cuda_raytrace.rs:20-58,
+ * cuda_rt.h:8-15) but with the CPU path's semantics
+ * (BoundingBox::get_object_intersection_for_ray, raytrace.rs:909-1010). */
+int rtmi_trace(rtmi_scene_t* scene, uint64_t n, const float* orig4, const float* dir4,
+               uint32_t* tri, float* t, uint32_t* face, rtmi_stats_t* stats);
+
+/* (c * 255.) as u8 per channel, RGB (raytrace.rs:1468-1473). */
+int rtmi_quantize(rtmi_scene_t* scene, const float* rgba_host, uint64_t npixels, uint8_t* rgb_host);
+
+/* Message of the last error on the calling thread ("" if none). */
+const char* rtmi_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTMI_H */

@@ -1,0 +1,91 @@
+"""ctypes loader for librtmi.so (HIP kernels + C ABI + C++ host mirror).
+
+The product path has no CPU fallback: if the library is missing this module
+raises, and every render entry point fails with the library's own error when
+no HIP device is visible.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "librtmi.so")
+
+
+class Stats(C.Structure):
+    """rtmi_stats_t (include/rtmi.h)."""
+    _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("full_tests", C.c_uint64), ("nodes", C.c_uint64), ("leaves", C.c_uint64),
+                ("kernel_ms", C.c_double), ("trace_ms", C.c_double), ("trace_launches", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+def build(force=False):
+    """Compile librtmi.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", _CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _CSRC, "-j4"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C rust_raytrace_amd/csrc). There is no CPU fallback for the render path.")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, f32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_float, C.c_int
+    L.rtmi_last_error.restype = C.c_char_p
+    L.rth_last_error.restype = C.c_char_p
+    L.rtmi_device_count.restype = i32
+    L.rth_to_radians.restype = f32
+    L.rth_to_radians.argtypes = [f32]
+    L.rth_scene_new.restype = vp
+    L.rth_scene_new.argtypes = [i32]
+    L.rth_scene_free.argtypes = [vp]
+    L.rth_num_tris.restype = u64
+    L.rth_num_tris.argtypes = [vp]
+    L.rth_make_color.argtypes = [C.c_uint8, C.c_uint8, C.c_uint8, vp]
+    L.rth_unit.argtypes = [vp, vp]
+    L.rth_create_transform.argtypes = [vp, f32, vp]
+    L.rth_create_viewport.argtypes = [u32, u32, f32, f32, vp, vp, f32, f32, vp]
+    L.rth_add_triangle.argtypes = [vp, vp, u32, vp, f32, f32, f32]
+    L.rth_add_obj.argtypes = [vp, C.c_char_p, vp, f32, vp, u32, vp, f32, f32, f32]
+    L.rth_add_disk.argtypes = [vp, vp, vp, f32, f32, u64, u32, vp, f32, f32, u32, vp, f32, f32, f32]
+    L.rth_add_sphere.argtypes = [vp, vp, f32, u64, u64, u32, vp, f32, f32, f32]
+    L.rth_populate_triangle_numbers.argtypes = [vp]
+    L.rth_build_bounding_box.argtypes = [vp, vp, f32, u64, u64, u32]
+    L.rth_build_trivial_bounding_box.argtypes = [vp, vp, f32]
+    L.rth_box_contains_polygon.argtypes = [vp, vp, f32, u64]
+    L.rth_face_contains_triangle.argtypes = [vp, vp, vp, f32, u64]
+    L.rth_get_triangles.argtypes = [vp, vp, vp, vp]
+    L.rth_tree_sizes.argtypes = [vp, vp, vp]
+    L.rth_tree_get.argtypes = [vp, vp, vp, vp]
+    L.rth_caster_config.argtypes = [vp, u64, i32, u32]
+    L.rth_caster_upload.argtypes = [vp]
+    L.rth_caster_walk_rows.argtypes = [vp, u32, u32, vp, u64, u64, u64, u64, vp, vp, vp]
+    L.rth_caster_walk_rows_device.argtypes = [vp, u32, u32, vp, u64, u64, u64, u64, vp, vp, vp, vp]
+    L.rth_caster_trace.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
+    L.rth_quantize.argtypes = [vp, u64, vp]
+    _lib = L
+    return L
+
+
+# every symbol include/rtmi.h and include/rtmi_host.h declare
+RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_set_options", "rtmi_render",
+                "rtmi_render_device", "rtmi_trace", "rtmi_quantize", "rtmi_last_error"]
+RTH_SYMBOLS = ["rth_last_error", "rth_make_color", "rth_unit", "rth_to_radians", "rth_create_transform",
+               "rth_create_viewport", "rth_scene_new", "rth_scene_free", "rth_num_tris", "rth_add_triangle", "rth_add_obj",
+               "rth_add_disk", "rth_add_sphere", "rth_populate_triangle_numbers", "rth_build_bounding_box",
+               "rth_build_trivial_bounding_box", "rth_box_contains_polygon", "rth_face_contains_triangle",
+               "rth_get_triangles", "rth_tree_sizes", "rth_tree_get", "rth_caster_config", "rth_caster_walk_rows",
+               "rth_caster_walk_rows_device", "rth_caster_trace", "rth_caster_upload", "rth_quantize"]

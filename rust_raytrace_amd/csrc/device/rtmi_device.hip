@@ -1,0 +1,867 @@
+// rtmi_device.hip — HIP kernels (gfx950) and the C ABI of include/rtmi.h.
+//
+// Pipeline for one batch of N = pixels*spp paths ("wavefront" formulation of
+// the reference's recursive project_ray, raytrace_lib/src/raytrace.rs:1256-1295):
+//
+//   k_gen     pixel_ray() for every (pixel, sample)        raytrace.rs:1374-1394
+//   for pass k = 0 .. maxdepth-1 (remaining depth = maxdepth-k):
+//     k_trace closest hit for every queued ray              raytrace.rs:909-1050, 400-439
+//     k_shade color_ray(): terminal colour, or push the surface and emit
+//             the bounce ray into the next queue, compacted with wave
+//             ballot + prefix sum                           raytrace.rs:1199-1254, 278-301
+//   k_accum   per pixel: ordered sum over samples * (1/spp) raytrace.rs:1414-1426
+//
+// The recursion `mix(c_1, mix(c_2, ...))` is evaluated inside-out when a path
+// terminates (fold over the per-path surface stack), which is bit-identical to
+// the nested calls; see DESIGN.md.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (strict IEEE f32:
+// correctly rounded / and sqrtf are hipcc defaults, contraction is not).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../../include/rtmi.h"
+#include "vec4.hpp"
+
+namespace rtmi {
+
+// ---------------------------------------------------------------- layout
+// HBM-resident scene (see DESIGN.md "Data layout"):
+//  nodes   : one 32-B record per BoundingBox, children of a box contiguous
+//  refs    : u32 triangle indices of all leaves, leaf ranges contiguous
+//  tplane  : 2 x float4 per triangle  (incenter.xyz, r2) (norm.xyz, material)
+//  tedge   : 4 x float4 per triangle  (side_k.xyz, side_len_k) x3, (thr_k x3, 0)
+//            thr_k = side_len_k * (1 - edge_thickness)      raytrace.rs:419
+//  mats    : 2 x float4 per distinct surface (color.rgb, alpha) (scattering, kind, 0, 0)
+struct DNode {
+    float cx, cy, cz, half;
+    uint32_t first, count, is_leaf, pad;
+};
+
+struct DScene {
+    const DNode* nodes;
+    const uint32_t* refs;
+    const float4* tplane;
+    const float4* tedge;
+    const float4* mats;
+    uint32_t nnodes, ntris, nmats, levels;
+};
+
+struct DView {
+    V4 orig, cam, vu, vv;
+    uint32_t width, height, maxdepth, spp;
+};
+
+#define RTMI_MAX_PASSES 32
+struct DCtrl {
+    uint32_t count[RTMI_MAX_PASSES + 1];  // rays queued for pass k
+    uint32_t head[RTMI_MAX_PASSES + 1];   // work-fetch cursor of pass k
+    unsigned long long rays;              // sum of count[] (the "Rays" statistic)
+    unsigned long long counters[5];       // box_tests tri_tests full_tests nodes leaves
+};
+
+// ---------------------------------------------------------------- ray for the hot loops
+struct RayK {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz;
+    float ow, dw;  // lane 3 of orig / dir (normally +0)
+    float qn, qd;  // lane-3 terms of norm.(incenter-orig) and norm.dir
+};
+
+__device__ inline RayK make_rayk(float4 o, float4 d) {
+    RayK r;
+    r.ox = o.x; r.oy = o.y; r.oz = o.z; r.ow = o.w;
+    r.dx = d.x; r.dy = d.y; r.dz = d.z; r.dw = d.w;
+    r.ix = 1.f / d.x; r.iy = 1.f / d.y; r.iz = 1.f / d.z;  // raytrace.rs:206-208
+    r.qn = 0.f * (0.f - o.w);
+    r.qd = 0.f * d.w;
+    return r;
+}
+
+// BoundingBox::collides (raytrace.rs:860-907)
+__device__ inline bool collides(float cx, float cy, float cz, float half, const RayK& r, float& tmin_o) {
+    float tmin = -FLT_MAX, tmax = FLT_MAX;
+    float a0 = (cx - r.ox) * r.ix, a1 = (cy - r.oy) * r.iy, a2 = (cz - r.oz) * r.iz;
+    float b0 = r.ix * half, b1 = r.iy * half, b2 = r.iz * half;
+    float t10 = a0 - b0, t20 = a0 + b0;
+    float t11 = a1 - b1, t21 = a1 + b1;
+    float t12 = a2 - b2, t22 = a2 + b2;
+    if (r.dx != 0.f) {
+        if (r.ix > 0.f) { tmin = t10; tmax = t20; } else { tmin = t20; tmax = t10; }
+    }
+    if (r.dy != 0.f) {
+        if (r.iy > 0.f) { tmin = fmaxf(tmin, t11); tmax = fminf(tmax, t21); }
+        else { tmin = fmaxf(tmin, t21); tmax = fminf(tmax, t11); }
+    }
+    if (r.dz != 0.f) {
+        if (r.iz > 0.f) { tmin = fmaxf(tmin, t12); tmax = fminf(tmax, t22); }
+        else { tmin = fmaxf(tmin, t22); tmax = fminf(tmax, t12); }
+    }
+    tmin_o = tmin;
+    return tmin < tmax;
+}
+
+// Triangle::intersects (raytrace.rs:400-439).  Returns hit; face bits: 1 = back, 2 = edge.
+template <bool COUNT>
+__device__ inline bool tri_test(const DScene& sc, uint32_t tri, const RayK& r, float& t_o, uint32_t& face_o,
+                                unsigned long long* cnt) {
+    const float4 p0 = sc.tplane[2 * tri], p1 = sc.tplane[2 * tri + 1];
+    float ax = p0.x - r.ox, ay = p0.y - r.oy, az = p0.z - r.oz;
+    float num = (((0.f + p1.x * ax) + p1.y * ay) + p1.z * az) + r.qn;
+    float den = (((0.f + p1.x * r.dx) + p1.y * r.dy) + p1.z * r.dz) + r.qd;
+    float t = num / den;
+    if (COUNT) cnt[1]++;
+    if (t < 0.f) return false;
+    float px = r.dx * t + r.ox, py = r.dy * t + r.oy, pz = r.dz * t + r.oz, pw = r.dw * t + r.ow;
+    float ix = px - p0.x, iy = py - p0.y, iz = pz - p0.z;
+    float l2 = ((ix * ix + iy * iy) + iz * iz) + pw * pw;
+    if (l2 > p0.w) return false;
+    if (COUNT) cnt[2]++;
+    const float4 e0 = sc.tedge[4 * tri], e1 = sc.tedge[4 * tri + 1], e2 = sc.tedge[4 * tri + 2], e3 = sc.tedge[4 * tri + 3];
+    float z = pw * 0.f;  // lane-3 product ip.w * side.w (side.w is +-0)
+    float d0 = ((ix * e0.x + iy * e0.y) + iz * e0.z) + z;
+    float d1 = ((ix * e1.x + iy * e1.y) + iz * e1.z) + z;
+    float d2 = ((ix * e2.x + iy * e2.y) + iz * e2.z) + z;
+    if (d0 > e0.w) return false;
+    if (d1 > e1.w) return false;
+    if (d2 > e2.w) return false;
+    bool edge = (d0 > e3.x) | (d1 > e3.y) | (d2 > e3.z);
+    t_o = t;
+    face_o = (den > 0.f ? 1u : 0u) | (edge ? 2u : 0u);
+    return true;
+}
+
+// ---------------------------------------------------------------- generic traversal (v1)
+// Iterative form of BoundingBox::get_object_intersection_for_ray
+// (raytrace.rs:909-1010).  One lane = one ray.  A frame is one inner box whose
+// colliding children wait in sorted order:
+//   w0 = index of its first child
+//   w1 = order word: 3-bit child slots, next child in bits 0-2 | count << 24 |
+//        has_hit << 28 | any_tmin_is_MAX << 29
+//   w2 = t of the frame's best hit, w3 = triangle | face << 30
+// Ancestors of the current frame live in LDS ([level][word][thread], so a
+// lane always hits its own bank).  The children's tmin are not kept: the
+// reference's skip rule `tmin < best_t` (raytrace.rs:965) is re-evaluated by
+// running collides() again on the one child about to be visited, which
+// returns the same float; since children are visited in ascending tmin and the
+// best t never grows, the first skipped child ends the frame.
+struct Frame { uint32_t first, w1; float t; uint32_t tri; };
+
+#define F_COUNT(w) (((w) >> 24) & 15u)
+#define F_HAS 0x10000000u
+#define F_ANYMAX 0x20000000u
+
+template <bool COUNT>
+__device__ inline Frame expand(const DScene& sc, uint32_t first, uint32_t count, const RayK& r, unsigned long long* cnt) {
+    float tm[8];
+    bool anymax = false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        tm[j] = INFINITY;
+        if (j < (int)count) {
+            const float4 g = *reinterpret_cast<const float4*>(&sc.nodes[first + j]);
+            float tmin;
+            if (COUNT) cnt[0]++;
+            if (collides(g.x, g.y, g.z, g.w, r, tmin)) {
+                tm[j] = tmin;
+                anymax |= (tmin == FLT_MAX);
+            }
+        }
+    }
+    // stable ascending rank (insertion sort of raytrace.rs:941-947): child i
+    // goes after every j < i with tm[j] <= tm[i] and every j > i with tm[j] < tm[i].
+    uint32_t order = 0, nh = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t rank = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j < i) rank += (tm[j] <= tm[i]) ? 1u : 0u;
+            if (j > i) rank += (tm[j] < tm[i]) ? 1u : 0u;
+        }
+        if (tm[i] != INFINITY) { order |= (uint32_t)i << (3u * rank); nh++; }
+    }
+    Frame f;
+    f.first = first;
+    f.w1 = order | (nh << 24) | (anymax ? F_ANYMAX : 0u);
+    f.t = 0.f;
+    f.tri = 0;
+    return f;
+}
+
+// get_box_min_time_intersection (raytrace.rs:1012-1050)
+template <bool COUNT>
+__device__ inline bool leaf_scan(const DScene& sc, uint32_t first, uint32_t count, const RayK& r, float& t_o,
+                                 uint32_t& tf_o, unsigned long long* cnt) {
+    bool have = false;
+    float bt = 0.f;
+    uint32_t btf = 0;
+    if (COUNT) cnt[4]++;
+    for (uint32_t i = 0; i < count; i++) {
+        uint32_t tri = sc.refs[first + i];
+        float t; uint32_t face;
+        if (tri_test<COUNT>(sc, tri, r, t, face, cnt)) {
+            if (!have || t < bt) { bt = t; btf = tri | (face << 30); }
+            have = true;
+        }
+    }
+    t_o = bt; tf_o = btf;
+    return have;
+}
+
+__device__ inline void merge(Frame& f, bool have, float t, uint32_t tf) {
+    // fold step of raytrace.rs:949-1007: first hit is taken, later ones replace iff strictly closer
+    if (have) {
+        if (!(f.w1 & F_HAS) || t < f.t) { f.t = t; f.tri = tf; }
+        f.w1 |= F_HAS;
+    }
+}
+
+template <bool COUNT>
+__device__ inline bool traverse(const DScene& sc, const RayK& r, uint32_t* lds, int nthreads, int tid, float& t_o,
+                                uint32_t& tf_o, unsigned long long* cnt) {
+    const DNode root = sc.nodes[0];
+    if (root.is_leaf) return leaf_scan<COUNT>(sc, root.first, root.count, r, t_o, tf_o, cnt);
+    if (COUNT) cnt[3]++;
+    Frame cur = expand<COUNT>(sc, root.first, root.count, r, cnt);
+    int sp = 0;
+    for (;;) {
+        if (F_COUNT(cur.w1) == 0) {
+            if (sp == 0) break;
+            const bool have = (cur.w1 & F_HAS) != 0;
+            const float ct = cur.t;
+            const uint32_t ctf = cur.tri;
+            sp--;
+            uint32_t* fr = lds + (size_t)sp * 4 * nthreads + tid;
+            cur.first = fr[0];
+            cur.w1 = fr[nthreads];
+            cur.t = __uint_as_float(fr[2 * nthreads]);
+            cur.tri = fr[3 * nthreads];
+            merge(cur, have, ct, ctf);
+            continue;
+        }
+        const uint32_t c = cur.w1 & 7u;
+        cur.w1 = ((cur.w1 & 0x00FFFFFFu) >> 3) | ((cur.w1 & 0xFF000000u) - (1u << 24));
+        const DNode ch = sc.nodes[cur.first + c];
+        if (cur.w1 & F_HAS) {
+            float tmin;
+            collides(ch.cx, ch.cy, ch.cz, ch.half, r, tmin);
+            if (!(tmin < cur.t)) { cur.w1 &= ~(15u << 24); continue; }  // raytrace.rs:965
+        } else if (cur.w1 & F_ANYMAX) {
+            float tmin;
+            collides(ch.cx, ch.cy, ch.cz, ch.half, r, tmin);
+            if (tmin == FLT_MAX) continue;  // raytrace.rs:986
+        }
+        if (ch.is_leaf) {
+            float t; uint32_t tf;
+            bool have = leaf_scan<COUNT>(sc, ch.first, ch.count, r, t, tf, cnt);
+            merge(cur, have, t, tf);
+        } else {
+            uint32_t* fr = lds + (size_t)sp * 4 * nthreads + tid;
+            fr[0] = cur.first;
+            fr[nthreads] = cur.w1;
+            fr[2 * nthreads] = __float_as_uint(cur.t);
+            fr[3 * nthreads] = cur.tri;
+            sp++;
+            if (COUNT) cnt[3]++;
+            cur = expand<COUNT>(sc, ch.first, ch.count, r, cnt);
+        }
+    }
+    t_o = cur.t; tf_o = cur.tri;
+    return (cur.w1 & F_HAS) != 0;
+}
+
+// Persistent closest-hit kernel: each wave pulls 64 queued rays at a time.
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_trace(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
+                                               DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
+                                               float* __restrict__ hit_t) {
+    extern __shared__ uint32_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t count = ctrl->count[pass];
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctrl->rays, (unsigned long long)count);
+    unsigned long long cnt[5] = {0, 0, 0, 0, 0};
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctrl->head[pass], 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= count) break;
+        const uint32_t i = base + lane;
+        if (i < count) {
+            const RayK r = make_rayk(qo[i], qd[i]);
+            float t = 0.f; uint32_t tf = 0;
+            bool have = traverse<COUNT>(sc, r, lds, blockDim.x, tid, t, tf, cnt);
+            hit_tf[i] = have ? tf : 0u;
+            hit_t[i] = have ? t : 0.f;
+        }
+    }
+    if (COUNT) {
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (cnt[k]) atomicAdd(&ctrl->counters[k], cnt[k]);
+    }
+}
+
+// ---------------------------------------------------------------- generation / shading
+struct RayV { V4 orig, dir; };
+// make_ray (raytrace.rs:201-210); inv_dir is recomputed by the trace kernel
+__device__ inline RayV make_ray(V4 orig, V4 dir) { return RayV{orig, vunit(dir)}; }
+
+// Viewport::pixel_ray (raytrace.rs:1374-1394), px = (row, col)
+__device__ inline RayV pixel_ray(const DView& v, uint32_t row, uint32_t col, uint64_t seed, uint32_t pixel, uint32_t sample) {
+    float px_x = (float)row, px_y = (float)col;
+    V4 vu_delta = vmul(v.vu, 1.f / (float)v.width);
+    V4 vv_delta = vmul(v.vv, 1.f / (float)v.height);
+    float u_off = 0.5f, v_off = 0.5f;
+    if (v.spp != 1) {
+        uint32_t w[4];
+        rng_block(seed, pixel, sample, 0, w);
+        u_off = u32_to_unit_f32(w[0]);
+        v_off = u32_to_unit_f32(w[1]);
+    }
+    V4 vu_frac = vmul(vu_delta, px_y + u_off);
+    V4 vv_frac = vmul(vv_delta, px_x + v_off);
+    V4 px_u = vadd(vadd(v.orig, vu_frac), vv_frac);
+    return make_ray(px_u, vunit(vsub(px_u, v.cam)));
+}
+
+__global__ void __launch_bounds__(256) k_gen(DView v, uint64_t seed, uint32_t pix0, uint32_t npaths,
+                                             float4* __restrict__ qo, float4* __restrict__ qd,
+                                             uint32_t* __restrict__ qpath, DCtrl* __restrict__ ctrl) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t path = blockIdx.x * blockDim.x + threadIdx.x; path < npaths; path += stride) {
+        const uint32_t pixel = pix0 + path / v.spp, sample = path % v.spp;
+        const uint32_t row = pixel / v.width, col = pixel % v.width;
+        RayV r = pixel_ray(v, row, col, seed, pixel, sample);
+        qo[path] = make_float4(r.orig.x, r.orig.y, r.orig.z, r.orig.w);
+        qd[path] = make_float4(r.dir.x, r.dir.y, r.dir.z, r.dir.w);
+        qpath[path] = path;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->count[0] = npaths;
+}
+
+// random_vec (raytrace.rs:188-192): k-th call of the path uses RNG block k
+__device__ inline V4 random_vec(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t k) {
+    uint32_t w[4];
+    rng_block(seed, pixel, sample, k, w);
+    return vunit(mk(u32_to_unit_f32(w[0]) - 0.5f, u32_to_unit_f32(w[1]) - 0.5f, u32_to_unit_f32(w[2]) - 0.5f));
+}
+// mix_color (raytrace.rs:299-301)
+__device__ inline V4 mix_color(V4 c1, V4 c2, float a) { return vadd(vmul(c1, 1.f - a), vmul(c2, a)); }
+
+// color_ray + the tail of project_ray for every ray of pass `pass`.
+__global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed, uint32_t pix0, uint32_t npaths, int pass,
+                                               const float4* __restrict__ qo, const float4* __restrict__ qd,
+                                               const uint32_t* __restrict__ qpath, const uint32_t* __restrict__ hit_tf,
+                                               const float* __restrict__ hit_t, float4* __restrict__ qo_n,
+                                               float4* __restrict__ qd_n, uint32_t* __restrict__ qpath_n,
+                                               uint16_t* __restrict__ mstack, float4* __restrict__ scol,
+                                               DCtrl* __restrict__ ctrl) {
+    const uint32_t count = ctrl->count[pass];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t depth = v.maxdepth - (uint32_t)pass;  // remaining depth of the rays of this pass (>= 1)
+    // round the loop bound up so that whole waves stay converged for the ballot
+    const uint32_t bound = (count + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < bound; i += stride) {
+        bool push = false;
+        RayV nr;
+        uint32_t path = 0;
+        if (i < count) {
+            path = qpath[i];
+            const uint32_t tf = hit_tf[i];
+            const uint32_t tri = tf & 0x3FFFFFFFu, face = tf >> 30;
+            const uint32_t pixel = pix0 + path / v.spp, sample = path % v.spp;
+            V4 c;
+            uint32_t npushed = (uint32_t)pass;
+            if (tri == 0) {
+                c = mk(128.f / 255.f, 180.f / 255.f, 255.f / 255.f);  // raytrace.rs:1264
+            } else if (face & 2u) {
+                c = mk(0.f / 255.f, 0.f / 255.f, 0.f / 255.f);  // edge faces are Solid black, raytrace.rs:452-457
+            } else {
+                const float4 p1 = sc.tplane[2 * tri + 1];
+                const uint32_t mat = __float_as_uint(p1.w);
+                const float4 m0 = sc.mats[2 * mat], m1 = sc.mats[2 * mat + 1];
+                const uint32_t kind = __float_as_uint(m1.y);
+                if (kind == RTMI_SOLID) {
+                    c = mk(m0.x, m0.y, m0.z);
+                } else {
+                    mstack[(size_t)pass * npaths + path] = (uint16_t)mat;
+                    npushed = (uint32_t)pass + 1;
+                    c = mk(0.f / 255.f, 0.f / 255.f, 0.f / 255.f);  // project_ray at depth 0, raytrace.rs:1261-1263
+                    if (depth - 1 != 0) {
+                        const float4 o4 = qo[i], d4 = qd[i];
+                        const V4 ro{o4.x, o4.y, o4.z, o4.w}, rd{d4.x, d4.y, d4.z, d4.w};
+                        const float t = hit_t[i];
+                        const V4 point = vadd(vmul(rd, t), ro);                      // Ray::at, raytrace.rs:227-229
+                        V4 norm = mk(p1.x, p1.y, p1.z);
+                        if (face & 1u) norm = vmul(norm, -1.f);                       // raytrace.rs:441-449
+                        const V4 rv = random_vec(seed, pixel, sample, (uint32_t)pass + 1);
+                        if (kind == RTMI_MATTE) {
+                            nr = make_ray(vadd(point, vmul(rv, 0.001f)), vadd(norm, rv));  // lambertian_ray, :292-297
+                        } else {
+                            const float ddot = fabsf(vdot(rd, norm));                 // reflect_ray, :278-290
+                            const V4 dir_p = vmul(norm, ddot);
+                            const V4 dir_o = vadd(rd, dir_p);
+                            const V4 reflect = vadd(dir_p, dir_o);
+                            const V4 rvf = vmul(rv, m1.x);
+                            const V4 reflect_dir = vunit(vadd(reflect, rvf));
+                            nr = make_ray(vadd(point, vmul(reflect_dir, 0.001f)), vunit(vadd(reflect, rvf)));
+                        }
+                        push = true;
+                    }
+                }
+            }
+            if (!push) {
+                // inside-out evaluation of the nested mix_color calls (raytrace.rs:1233-1251)
+                for (int j = (int)npushed - 1; j >= 0; j--) {
+                    const uint32_t mj = mstack[(size_t)j * npaths + path];
+                    const float4 mm = sc.mats[2 * mj];
+                    c = mix_color(mk(mm.x, mm.y, mm.z), c, mm.w);
+                }
+                scol[path] = make_float4(c.x, c.y, c.z, c.w);
+            }
+        }
+        // compact surviving rays into the next queue: ballot + prefix sum, one atomic per wave
+        const unsigned long long mask = __ballot(push);
+        if (mask) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&ctrl->count[pass + 1], (uint32_t)__popcll(mask));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (push) {
+                const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                qo_n[slot] = make_float4(nr.orig.x, nr.orig.y, nr.orig.z, nr.orig.w);
+                qd_n[slot] = make_float4(nr.dir.x, nr.dir.y, nr.dir.z, nr.dir.w);
+                qpath_n[slot] = path;
+            }
+        }
+    }
+}
+
+// walk_ray_set's per-pixel accumulation (raytrace.rs:1414-1426)
+__global__ void __launch_bounds__(256) k_accum(uint32_t npixels, uint32_t spp, const float4* __restrict__ scol,
+                                               float4* __restrict__ out) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npixels; p += stride) {
+        V4 acc = mk(0.f, 0.f, 0.f);
+        for (uint32_t s = 0; s < spp; s++) {
+            const float4 c = scol[(size_t)p * spp + s];
+            acc = vadd(acc, V4{c.x, c.y, c.z, c.w});
+        }
+        const V4 px = vmul(acc, 1.f / (float)spp);
+        out[p] = make_float4(px.x, px.y, px.z, px.w);
+    }
+}
+
+// write_png's quantisation (raytrace.rs:1468-1473): `as u8` truncates and saturates, NaN -> 0
+__global__ void __launch_bounds__(256) k_quantize(uint64_t npixels, const float4* __restrict__ in, uint8_t* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npixels; p += stride) {
+        const float4 c = in[p];
+        const float ch[3] = {c.x * 255.f, c.y * 255.f, c.z * 255.f};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float x = ch[k];
+            out[p * 3 + k] = (x != x) ? 0 : (x <= 0.f ? 0 : (x >= 255.f ? 255 : (uint8_t)x));
+        }
+    }
+}
+
+// Explicit-ray entry (rtmi_trace): queue = the caller's rays
+__global__ void k_set_count(DCtrl* ctrl, uint32_t n) { ctrl->count[0] = n; }
+
+// ---------------------------------------------------------------- host side of the ABI
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? RTMI_ERR_OOM : RTMI_ERR_NO_DEVICE,                 \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                            \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t want) {
+        if (want <= n) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace rtmi
+
+using namespace rtmi;
+
+struct rtmi_scene {
+    int device = 0;
+    uint32_t options = 0;
+    DScene d{};
+    DevBuf<DNode> nodes;
+    DevBuf<uint32_t> refs;
+    DevBuf<float4> tplane, tedge, mats;
+    // per-batch workspace
+    size_t cap = 0;
+    uint32_t cap_depth = 0;
+    DevBuf<float4> qo[2], qd[2], scol, tile;
+    DevBuf<uint32_t> qpath[2], hit_tf;
+    DevBuf<float> hit_t;
+    DevBuf<uint16_t> mstack;
+    DevBuf<DCtrl> ctrl;
+    DevBuf<uint8_t> qbytes;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> pass_ev;  // start/stop of the trace kernel of every pass
+    int num_cu = 256;
+    int trace_block = 256;
+    size_t trace_lds = 0;
+};
+
+static size_t env_size(const char* name, size_t dflt) {
+    const char* s = getenv(name);
+    if (!s || !*s) return dflt;
+    char* end = nullptr;
+    unsigned long long v = strtoull(s, &end, 10);
+    return (end && *end == '\0' && v > 0) ? (size_t)v : dflt;
+}
+
+extern "C" {
+
+const char* rtmi_last_error(void) { return g_err.c_str(); }
+
+int rtmi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_box_t* boxes, uint64_t nboxes,
+                      const uint32_t* tri_refs, uint64_t nrefs, int device, rtmi_scene_t** out) {
+    if (!out) return fail(RTMI_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!tris || ntris < 1) return fail(RTMI_ERR_INVALID, "need at least the sentinel triangle (index 0)");
+    if (!boxes || nboxes < 1) return fail(RTMI_ERR_INVALID, "need at least the root box");
+    if (nrefs > 0 && !tri_refs) return fail(RTMI_ERR_INVALID, "tri_refs is NULL");
+    if (ntris >= (1ull << 30)) return fail(RTMI_ERR_UNSUPPORTED, "more than 2^30 triangles");
+    if (nboxes >= (1ull << 32) || nrefs >= (1ull << 32)) return fail(RTMI_ERR_UNSUPPORTED, "tree too large for 32-bit indices");
+
+    // ---- validate the tree, compute inner depth (levels of the LDS stack)
+    std::vector<uint32_t> depth(nboxes, 0xFFFFFFFFu);
+    depth[0] = 0;
+    uint32_t max_inner_depth = 0;
+    for (uint64_t i = 0; i < nboxes; i++) {
+        const rtmi_box_t& b = boxes[i];
+        if (depth[i] == 0xFFFFFFFFu) return fail(RTMI_ERR_INVALID, "box " + std::to_string(i) + " is not reachable from an earlier box");
+        if (b.is_leaf) {
+            if ((uint64_t)b.first + b.count > nrefs) return fail(RTMI_ERR_INVALID, "leaf triangle range out of bounds");
+            for (uint32_t k = 0; k < b.count; k++)
+                if (tri_refs[b.first + k] >= ntris) return fail(RTMI_ERR_INVALID, "triangle index out of range");
+        } else {
+            // the reference's boxmap has 8 slots (raytrace.rs:929): more children would panic there
+            if (b.count < 1 || b.count > 8) return fail(RTMI_ERR_INVALID, "inner box must have 1..8 children");
+            if (b.first <= i || (uint64_t)b.first + b.count > nboxes) return fail(RTMI_ERR_INVALID, "child range must follow its parent");
+            for (uint32_t k = 0; k < b.count; k++) {
+                if (depth[b.first + k] != 0xFFFFFFFFu) return fail(RTMI_ERR_INVALID, "box has two parents");
+                depth[b.first + k] = depth[i] + 1;
+            }
+            max_inner_depth = std::max(max_inner_depth, depth[i]);
+        }
+    }
+    const uint32_t levels = std::max<uint32_t>(1u, max_inner_depth);
+    int block = 256;
+    if ((size_t)levels * 16 * 256 > 40 * 1024) block = 64;
+    if ((size_t)levels * 16 * block > 64 * 1024) return fail(RTMI_ERR_UNSUPPORTED, "octree deeper than the LDS stack allows");
+
+    // ---- device records
+    std::vector<DNode> hn(nboxes);
+    for (uint64_t i = 0; i < nboxes; i++) {
+        const rtmi_box_t& b = boxes[i];
+        hn[i] = DNode{b.orig[0], b.orig[1], b.orig[2], b.len2, b.first, b.count, b.is_leaf ? 1u : 0u, 0u};
+    }
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t> matmap;
+    std::vector<float4> hm, hp(2 * ntris), he(4 * ntris);
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    auto fbits = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+    for (uint64_t i = 0; i < ntris; i++) {
+        const rtmi_triangle_t& t = tris[i];
+        if (t.surface_kind > RTMI_REFLECTIVE) return fail(RTMI_ERR_INVALID, "unknown surface kind");
+        // fields a kind does not carry do not distinguish materials
+        const float alpha = t.surface_kind == RTMI_SOLID ? 0.f : t.alpha;
+        const float scat = t.surface_kind == RTMI_REFLECTIVE ? t.scattering : 0.f;
+        auto key = std::make_tuple(t.surface_kind, bits(t.color[0]), bits(t.color[1]), bits(t.color[2]), bits(alpha), bits(scat));
+        auto it = matmap.find(key);
+        uint32_t mid;
+        if (it == matmap.end()) {
+            mid = (uint32_t)matmap.size();
+            matmap.emplace(key, mid);
+            hm.push_back(make_float4(t.color[0], t.color[1], t.color[2], alpha));
+            hm.push_back(make_float4(scat, fbits(t.surface_kind), 0.f, 0.f));
+        } else mid = it->second;
+        hp[2 * i] = make_float4(t.incenter[0], t.incenter[1], t.incenter[2], t.bounding_r2);
+        hp[2 * i + 1] = make_float4(t.norm[0], t.norm[1], t.norm[2], fbits(mid));
+        const float om = 1.f - t.edge_thickness;  // raytrace.rs:419
+        for (int k = 0; k < 3; k++) he[4 * i + k] = make_float4(t.sides[k][0], t.sides[k][1], t.sides[k][2], t.side_lens[k]);
+        he[4 * i + 3] = make_float4(t.side_lens[0] * om, t.side_lens[1] * om, t.side_lens[2] * om, 0.f);
+    }
+    if (matmap.size() > 65535) return fail(RTMI_ERR_UNSUPPORTED, "more than 65535 distinct surfaces");
+
+    int ndev = rtmi_device_count();
+    if (ndev <= 0) return fail(RTMI_ERR_NO_DEVICE, "no HIP device visible: the MI355X kernels cannot run (there is no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(RTMI_ERR_INVALID, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+
+    rtmi_scene* s = new (std::nothrow) rtmi_scene();
+    if (!s) return fail(RTMI_ERR_OOM, "host allocation failed");
+    s->device = device;
+    s->trace_block = block;
+    s->trace_lds = (size_t)levels * 16 * block;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cu = prop.multiProcessorCount;
+    auto up = [&](auto& buf, const auto& host) -> hipError_t {
+        hipError_t e = buf.ensure(std::max<size_t>(host.size(), 1));
+        if (e != hipSuccess) return e;
+        if (host.empty()) return hipSuccess;
+        return hipMemcpy(buf.p, host.data(), host.size() * sizeof(host[0]), hipMemcpyHostToDevice);
+    };
+    std::vector<uint32_t> hrefs(tri_refs, tri_refs + nrefs);
+    hipError_t e = up(s->nodes, hn);
+    if (e == hipSuccess) e = up(s->refs, hrefs);
+    if (e == hipSuccess) e = up(s->tplane, hp);
+    if (e == hipSuccess) e = up(s->tedge, he);
+    if (e == hipSuccess) e = up(s->mats, hm);
+    if (e == hipSuccess) e = s->ctrl.ensure(1);
+    for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&s->ev[k]);
+    if (e != hipSuccess) {
+        std::string msg = std::string("scene upload: ") + hipGetErrorString(e);
+        rtmi_scene_destroy(s);
+        return fail(e == hipErrorOutOfMemory ? RTMI_ERR_OOM : RTMI_ERR_NO_DEVICE, msg);
+    }
+    s->d = DScene{s->nodes.p, s->refs.p, s->tplane.p, s->tedge.p, s->mats.p,
+                  (uint32_t)nboxes, (uint32_t)ntris, (uint32_t)matmap.size(), levels};
+    *out = s;
+    return RTMI_OK;
+}
+
+int rtmi_scene_destroy(rtmi_scene_t* s) {
+    if (!s) return RTMI_OK;
+    (void)hipSetDevice(s->device);
+    s->nodes.release(); s->refs.release(); s->tplane.release(); s->tedge.release(); s->mats.release();
+    for (int k = 0; k < 2; k++) { s->qo[k].release(); s->qd[k].release(); s->qpath[k].release(); }
+    s->scol.release(); s->tile.release(); s->hit_tf.release(); s->hit_t.release(); s->mstack.release();
+    s->ctrl.release(); s->qbytes.release();
+    for (int k = 0; k < 4; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
+    for (hipEvent_t e : s->pass_ev) (void)hipEventDestroy(e);
+    delete s;
+    return RTMI_OK;
+}
+
+int rtmi_scene_set_options(rtmi_scene_t* s, uint32_t options) {
+    if (!s) return fail(RTMI_ERR_INVALID, "scene is NULL");
+    s->options = options;
+    return RTMI_OK;
+}
+
+static int ensure_workspace(rtmi_scene* s, size_t cap, uint32_t maxdepth) {
+    if (cap <= s->cap && maxdepth <= s->cap_depth) return RTMI_OK;
+    cap = std::max(cap, s->cap);
+    maxdepth = std::max(maxdepth, s->cap_depth);
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(s->qo[k].ensure(cap));
+        HIPCHK(s->qd[k].ensure(cap));
+        HIPCHK(s->qpath[k].ensure(cap));
+    }
+    HIPCHK(s->scol.ensure(cap));
+    HIPCHK(s->hit_tf.ensure(cap));
+    HIPCHK(s->hit_t.ensure(cap));
+    HIPCHK(s->mstack.ensure(cap * (size_t)maxdepth));
+    s->cap = cap;
+    s->cap_depth = maxdepth;
+    return RTMI_OK;
+}
+
+extern "C++" {
+template <bool COUNT>
+static void launch_trace(rtmi_scene* s, hipStream_t st, const float4* qo, const float4* qd, int pass) {
+    // persistent grid: enough blocks to fill every CU at the occupancy LDS allows
+    const int per_cu = s->trace_block == 256 ? 4 : 16;
+    dim3 grid((unsigned)(s->num_cu * per_cu)), block((unsigned)s->trace_block);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<COUNT>), grid, block, s->trace_lds, st, s->d, qo, qd, s->ctrl.p, pass,
+                       s->hit_tf.p, s->hit_t.p);
+}
+}  // extern "C++"
+
+static int read_stats(rtmi_scene* s, hipStream_t st, rtmi_stats_t* stats, float kernel_ms, float trace_ms, uint32_t launches) {
+    DCtrl h;
+    HIPCHK(hipMemcpyAsync(&h, s->ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (stats) {
+        stats->rays += h.rays;
+        stats->box_tests += h.counters[0]; stats->tri_tests += h.counters[1]; stats->full_tests += h.counters[2];
+        stats->nodes += h.counters[3]; stats->leaves += h.counters[4];
+        stats->kernel_ms += kernel_ms; stats->trace_ms += trace_ms; stats->trace_launches += launches;
+    }
+    return RTMI_OK;
+}
+
+int rtmi_render_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t seed, uint32_t row0, uint32_t nrows,
+                       void* out_device, void* hip_stream, rtmi_stats_t* stats) {
+    if (!s || !vp || !out_device) return fail(RTMI_ERR_INVALID, "NULL argument");
+    if (vp->width == 0 || vp->height == 0) return fail(RTMI_ERR_INVALID, "empty viewport");
+    if ((uint64_t)row0 + nrows > vp->height) return fail(RTMI_ERR_INVALID, "row range outside the viewport");
+    if (vp->samples_per_pixel == 0) return fail(RTMI_ERR_INVALID, "samples_per_pixel must be >= 1");  // reference: 1/0 -> NaN image
+    if (vp->maxdepth > RTMI_MAX_PASSES) return fail(RTMI_ERR_UNSUPPORTED, "maxdepth above 32");
+    if ((uint64_t)vp->width * vp->height >= (1ull << 32)) return fail(RTMI_ERR_UNSUPPORTED, "more than 2^32 pixels");
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const uint32_t W = vp->width, spp = vp->samples_per_pixel, maxdepth = vp->maxdepth;
+    const uint64_t npix = (uint64_t)nrows * W;
+    float4* out = (float4*)out_device;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (npix == 0) return RTMI_OK;
+    if (maxdepth == 0) {  // project_ray returns black immediately (raytrace.rs:1261-1263); acc*(1/spp) of zeros
+        HIPCHK(hipMemsetAsync(out, 0, npix * sizeof(float4), st));
+        HIPCHK(hipStreamSynchronize(st));
+        return RTMI_OK;
+    }
+    // batch = whole pixels with all their samples
+    const size_t want_paths = env_size("RTMI_BATCH_PATHS", (size_t)16 << 20);
+    uint64_t pix_per_batch = std::max<uint64_t>(1, want_paths / spp);
+    pix_per_batch = std::min<uint64_t>(pix_per_batch, npix);
+    if (pix_per_batch * spp >= (1ull << 31)) return fail(RTMI_ERR_UNSUPPORTED, "batch above 2^31 paths");
+    int rc = ensure_workspace(s, (size_t)(pix_per_batch * spp), maxdepth);
+    if (rc != RTMI_OK) return rc;
+
+    DView dv;
+    dv.orig = mk(vp->orig[0], vp->orig[1], vp->orig[2]);
+    dv.cam = mk(vp->cam[0], vp->cam[1], vp->cam[2]);
+    dv.vu = mk(vp->vu[0], vp->vu[1], vp->vu[2]);
+    dv.vv = mk(vp->vv[0], vp->vv[1], vp->vv[2]);
+    dv.width = W; dv.height = vp->height; dv.maxdepth = maxdepth; dv.spp = spp;
+
+    const bool counting = (s->options & RTMI_OPT_COUNTERS) != 0;
+    const unsigned ew_blocks = (unsigned)(s->num_cu * 8);
+    float kernel_ms = 0.f, trace_ms = 0.f;
+    uint32_t launches = 0;
+    while (s->pass_ev.size() < 2 * (size_t)maxdepth) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        s->pass_ev.push_back(e);
+    }
+    for (uint64_t p0 = 0; p0 < npix; p0 += pix_per_batch) {
+        const uint32_t np = (uint32_t)std::min<uint64_t>(pix_per_batch, npix - p0);
+        const uint32_t npaths = np * spp;
+        const uint32_t pix0 = (uint32_t)((uint64_t)row0 * W + p0);
+        HIPCHK(hipMemsetAsync(s->ctrl.p, 0, sizeof(DCtrl), st));
+        HIPCHK(hipEventRecord(s->ev[0], st));
+        hipLaunchKernelGGL(k_gen, dim3(ew_blocks), dim3(256), 0, st, dv, seed, pix0, npaths, s->qo[0].p, s->qd[0].p, s->qpath[0].p, s->ctrl.p);
+        float tms = 0.f;
+        for (uint32_t pass = 0; pass < maxdepth; pass++) {
+            const int a = pass & 1, b = a ^ 1;
+            HIPCHK(hipEventRecord(s->pass_ev[2 * pass], st));
+            if (counting) launch_trace<true>(s, st, s->qo[a].p, s->qd[a].p, (int)pass);
+            else launch_trace<false>(s, st, s->qo[a].p, s->qd[a].p, (int)pass);
+            HIPCHK(hipEventRecord(s->pass_ev[2 * pass + 1], st));
+            hipLaunchKernelGGL(k_shade, dim3(ew_blocks), dim3(256), 0, st, s->d, dv, seed, pix0, npaths, (int)pass,
+                               s->qo[a].p, s->qd[a].p, s->qpath[a].p, s->hit_tf.p, s->hit_t.p, s->qo[b].p, s->qd[b].p,
+                               s->qpath[b].p, s->mstack.p, s->scol.p, s->ctrl.p);
+            launches++;
+        }
+        hipLaunchKernelGGL(k_accum, dim3(ew_blocks), dim3(256), 0, st, np, spp, s->scol.p, out + p0);
+        HIPCHK(hipEventRecord(s->ev[1], st));
+        HIPCHK(hipGetLastError());
+        rtmi_stats_t bs; memset(&bs, 0, sizeof(bs));
+        rc = read_stats(s, st, &bs, 0.f, 0.f, 0);
+        if (rc != RTMI_OK) return rc;
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+        for (uint32_t pass = 0; pass < maxdepth; pass++) {
+            float pm = 0.f;
+            HIPCHK(hipEventElapsedTime(&pm, s->pass_ev[2 * pass], s->pass_ev[2 * pass + 1]));
+            tms += pm;
+        }
+        kernel_ms += ms; trace_ms += tms;
+        if (stats) {
+            stats->rays += bs.rays; stats->box_tests += bs.box_tests; stats->tri_tests += bs.tri_tests;
+            stats->full_tests += bs.full_tests; stats->nodes += bs.nodes; stats->leaves += bs.leaves;
+        }
+    }
+    if (stats) { stats->kernel_ms = kernel_ms; stats->trace_ms = trace_ms; stats->trace_launches = launches; }
+    return RTMI_OK;
+}
+
+int rtmi_render(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t seed, uint32_t row0, uint32_t nrows,
+                float* out_host, rtmi_stats_t* stats) {
+    if (!s || !vp || !out_host) return fail(RTMI_ERR_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(s->device));
+    const uint64_t npix = (uint64_t)nrows * vp->width;
+    if (npix == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return RTMI_OK; }
+    HIPCHK(s->tile.ensure(npix));
+    int rc = rtmi_render_device(s, vp, seed, row0, nrows, s->tile.p, nullptr, stats);
+    if (rc != RTMI_OK) return rc;
+    HIPCHK(hipMemcpy(out_host, s->tile.p, npix * sizeof(float4), hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+int rtmi_trace(rtmi_scene_t* s, uint64_t n, const float* orig4, const float* dir4, uint32_t* tri, float* t,
+               uint32_t* face, rtmi_stats_t* stats) {
+    if (!s) return fail(RTMI_ERR_INVALID, "scene is NULL");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (n == 0) return RTMI_OK;
+    if (!orig4 || !dir4 || !tri || !t || !face) return fail(RTMI_ERR_INVALID, "NULL argument");
+    if (n >= (1ull << 31)) return fail(RTMI_ERR_UNSUPPORTED, "more than 2^31 rays per call");
+    HIPCHK(hipSetDevice(s->device));
+    int rc = ensure_workspace(s, (size_t)n, 1);
+    if (rc != RTMI_OK) return rc;
+    hipStream_t st = nullptr;
+    HIPCHK(hipMemcpyAsync(s->qo[0].p, orig4, n * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->qd[0].p, dir4, n * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(s->ctrl.p, 0, sizeof(DCtrl), st));
+    hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, s->ctrl.p, (uint32_t)n);
+    HIPCHK(hipEventRecord(s->ev[0], st));
+    if (s->options & RTMI_OPT_COUNTERS) launch_trace<true>(s, st, s->qo[0].p, s->qd[0].p, 0);
+    else launch_trace<false>(s, st, s->qo[0].p, s->qd[0].p, 0);
+    HIPCHK(hipEventRecord(s->ev[1], st));
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> tf(n);
+    HIPCHK(hipMemcpyAsync(tf.data(), s->hit_tf.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(t, s->hit_t.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (uint64_t i = 0; i < n; i++) { tri[i] = tf[i] & 0x3FFFFFFFu; face[i] = tf[i] >> 30; }
+    // face encoding of the ABI: 0 front 1 back 2 edge-front 3 edge-back (bit0 = back, bit1 = edge)
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+    return read_stats(s, st, stats, ms, ms, 1);
+}
+
+int rtmi_quantize(rtmi_scene_t* s, const float* rgba_host, uint64_t npixels, uint8_t* rgb_host) {
+    if (!s) return fail(RTMI_ERR_INVALID, "scene is NULL");
+    if (npixels == 0) return RTMI_OK;
+    if (!rgba_host || !rgb_host) return fail(RTMI_ERR_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(s->tile.ensure(npixels));
+    HIPCHK(s->qbytes.ensure(npixels * 3));
+    HIPCHK(hipMemcpy(s->tile.p, rgba_host, npixels * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_quantize, dim3((unsigned)(s->num_cu * 8)), dim3(256), 0, nullptr, (uint64_t)npixels, s->tile.p, s->qbytes.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(rgb_host, s->qbytes.p, npixels * 3, hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,266 @@
+"""Python view of the host-side mirror of rust_raytrace's `raytrace` module.
+
+Names follow raytrace_lib/src/raytrace.rs: make_color, create_transform,
+create_viewport, Scene (tris + boxes), make_disk / make_sphere / parse_obj
+(as Scene.extend_* helpers, since triangles live in the C++ Scene),
+build_bounding_box, build_trivial_bounding_box, and the RayCaster plug-in
+`HipRayCaster` whose walk_rays() runs the MI355X kernels through the C ABI.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _ffi
+
+SOLID, MATTE, REFLECTIVE = 0, 1, 2
+OPT_COUNTERS, OPT_GENERIC = 1, 2
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(rc):
+    if rc != 0:
+        raise RuntimeError(_ffi.lib().rth_last_error().decode())
+
+
+def make_color(r, g, b):
+    """raytrace.rs:176-180"""
+    out = np.zeros(3, np.float32)
+    _ffi.lib().rth_make_color(r, g, b, _p(out))
+    return out
+
+
+def unit(v):
+    out = np.zeros(3, np.float32)
+    _ffi.lib().rth_unit(_p(_f(v)), _p(out))
+    return out
+
+
+def to_radians(deg):
+    return float(_ffi.lib().rth_to_radians(deg))
+
+
+def create_transform(direction, d_roll):
+    """raytrace.rs:1320-1341 -> 9 floats (three basis rows)."""
+    out = np.zeros(9, np.float32)
+    _ffi.lib().rth_create_transform(_p(_f(direction)), d_roll, _p(out))
+    return out
+
+
+class SurfaceKind:
+    """raytrace.rs:303-308"""
+
+    def __init__(self, kind, color, alpha=0.0, scattering=0.0):
+        self.kind, self.color, self.alpha, self.scattering = kind, _f(color), float(alpha), float(scattering)
+
+    @staticmethod
+    def Solid(color):
+        return SurfaceKind(SOLID, color)
+
+    @staticmethod
+    def Matte(color, alpha):
+        return SurfaceKind(MATTE, color, alpha)
+
+    @staticmethod
+    def Reflective(scattering, color, alpha):
+        return SurfaceKind(REFLECTIVE, color, alpha, scattering)
+
+    def args(self):
+        return (self.kind, _p(self.color), self.alpha, self.scattering)
+
+
+class Viewport:
+    """raytrace.rs:1305-1318"""
+
+    def __init__(self, width, height, vp12, maxdepth, samples_per_pixel):
+        self.width, self.height = int(width), int(height)
+        self.vp12 = _f(vp12)
+        self.maxdepth, self.samples_per_pixel = int(maxdepth), int(samples_per_pixel)
+
+
+def create_viewport(px, size, pos, direction, fov, c_roll, maxdepth, samples):
+    """raytrace.rs:1343-1370"""
+    out = np.zeros(12, np.float32)
+    _ffi.lib().rth_create_viewport(px[0], px[1], size[0], size[1], _p(_f(pos)), _p(_f(direction)), fov, c_roll, _p(out))
+    return Viewport(px[0], px[1], out, maxdepth, samples)
+
+
+class Scene:
+    """raytrace.rs:1297-1303: tris + boxes (held by the C++ mirror)."""
+
+    def __init__(self, with_dummy=True):
+        self.h = C.c_void_p(_ffi.lib().rth_scene_new(1 if with_dummy else 0))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _ffi.lib().rth_scene_free(self.h)
+            self.h = None
+
+    # --- Scene.tris
+    def num_tris(self):
+        return int(_ffi.lib().rth_num_tris(self.h))
+
+    def push_triangle(self, points, surface, edge_thickness):
+        """obj_data.push(make_triangle(points, surface, edge_thickness))"""
+        _chk(_ffi.lib().rth_add_triangle(self.h, _p(_f(points).reshape(9)), *surface.args(), edge_thickness))
+
+    def extend_parse_obj(self, path, offset, scale, transform, surface, edge_thickness):
+        """obj_data.extend(obj_parser::parse_obj(...)) — obj_parser.rs:47-73"""
+        _chk(_ffi.lib().rth_add_obj(self.h, path.encode(), _p(_f(offset)), scale, _p(_f(transform)), *surface.args(),
+                                    edge_thickness))
+
+    def extend_make_disk(self, orig, norm, r, d, num_tris, surface, side_surface, edge_thickness):
+        """obj_data.extend(make_disk(...)) — raytrace.rs:531-592"""
+        _chk(_ffi.lib().rth_add_disk(self.h, _p(_f(orig)), _p(_f(norm)), r, d, num_tris, *surface.args(),
+                                     *side_surface.args(), edge_thickness))
+
+    def extend_make_sphere(self, orig, r, lat_lon, surface, edge_thickness):
+        """obj_data.extend(make_sphere(...)) — raytrace.rs:464-529"""
+        _chk(_ffi.lib().rth_add_sphere(self.h, _p(_f(orig)), r, lat_lon[0], lat_lon[1], *surface.args(), edge_thickness))
+
+    def populate_triangle_numbers(self):
+        _ffi.lib().rth_populate_triangle_numbers(self.h)
+
+    # --- Scene.boxes
+    def build_bounding_box(self, orig, len2, maxdepth, minobjs, threads=0):
+        """raytrace.rs:790-845"""
+        _chk(_ffi.lib().rth_build_bounding_box(self.h, _p(_f(orig)), len2, maxdepth, minobjs, threads))
+
+    def build_trivial_bounding_box(self, orig, len2):
+        """raytrace.rs:847-856"""
+        _chk(_ffi.lib().rth_build_trivial_bounding_box(self.h, _p(_f(orig)), len2))
+
+    def box_contains_polygon(self, orig, len2, tri):
+        return bool(_ffi.lib().rth_box_contains_polygon(self.h, _p(_f(orig)), len2, tri))
+
+    def face_contains_triangle(self, p, norm, len2, tri):
+        return bool(_ffi.lib().rth_face_contains_triangle(self.h, _p(_f(p)), _p(_f(norm)), len2, tri))
+
+    # --- inspection
+    def triangles(self):
+        n = self.num_tris()
+        rec = np.zeros((n, 29), np.float32)
+        kinds = np.zeros(n, np.int32)
+        surf = np.zeros((n, 5), np.float32)
+        _ffi.lib().rth_get_triangles(self.h, _p(rec), _p(kinds), _p(surf))
+        return rec, kinds, surf
+
+    def tree(self):
+        nb, nr = C.c_uint64(0), C.c_uint64(0)
+        _ffi.lib().rth_tree_sizes(self.h, C.byref(nb), C.byref(nr))
+        geo = np.zeros((nb.value, 4), np.float32)
+        topo = np.zeros((nb.value, 4), np.uint32)
+        refs = np.zeros(max(nr.value, 1), np.uint32)
+        _ffi.lib().rth_tree_get(self.h, _p(geo), _p(topo), _p(refs))
+        return geo, topo, refs[: nr.value]
+
+    def tree_stats(self):
+        _, topo, refs = self.tree()
+        leaf = topo[:, 2] == 1
+        return dict(inner=int((~leaf).sum()), leaves=int(leaf.sum()), refs=int(len(refs)),
+                    maxdepth=int(topo[:, 3].max()) if len(topo) else 0)
+
+
+class ProgressCtx:
+    """What progress.rs:157-184 reports."""
+
+    def __init__(self, total_rays, seconds, stats):
+        self.total_rays, self.seconds, self.stats = total_rays, seconds, stats
+
+    def stats_line(self):
+        m = self.total_rays / 1e6
+        return f"Processed {m:.3f} million rays in {self.seconds:.3f} seconds. {m / max(self.seconds, 1e-12):.3f} million rays/s"
+
+
+class HipRayCaster:
+    """impl RayCaster (raytrace.rs:1128-1165) on MI355X.
+
+    walk_rays(v, s, data, threads, show_progress) fills `data` ((H, W, 4) f32,
+    the reference's `&mut [Color]`) and returns a ProgressCtx.  `threads` is
+    accepted and ignored, as the reference's CudaRayCaster does.
+    """
+
+    def __init__(self, seed=1, device=0, options=0):
+        self.seed, self.device, self.options = int(seed), int(device), int(options)
+
+    def _config(self, s):
+        _chk(_ffi.lib().rth_caster_config(s.h, self.seed, self.device, self.options))
+
+    def walk_rays(self, v, s, data, threads=1, show_progress=False):
+        return self.walk_rows(v, s, 0, v.height, data)
+
+    def walk_rows(self, v, s, row0, nrows, data):
+        """Rows [row0, row0+nrows) only — the unit of multi-GPU image tiling."""
+        if data.dtype != np.float32 or not data.flags.c_contiguous or data.size != nrows * v.width * 4:
+            raise ValueError("data must be a C-contiguous float32 array of nrows*width*4 elements")
+        self._config(s)
+        st = _ffi.Stats()
+        wall = C.c_double(0)
+        _chk(_ffi.lib().rth_caster_walk_rows(s.h, v.width, v.height, _p(v.vp12), v.maxdepth, v.samples_per_pixel, row0,
+                                             nrows, _p(data), C.byref(st), C.byref(wall)))
+        return ProgressCtx(st.rays, wall.value, st.as_dict())
+
+    def walk_rows_device(self, v, s, row0, nrows, out_ptr, stream_ptr=None):
+        """Same, writing nrows*width float4 of device memory at `out_ptr` on HIP stream `stream_ptr`."""
+        self._config(s)
+        st = _ffi.Stats()
+        wall = C.c_double(0)
+        _chk(_ffi.lib().rth_caster_walk_rows_device(s.h, v.width, v.height, _p(v.vp12), v.maxdepth, v.samples_per_pixel,
+                                                    row0, nrows, C.c_void_p(out_ptr), C.c_void_p(stream_ptr or 0),
+                                                    C.byref(st), C.byref(wall)))
+        return ProgressCtx(st.rays, wall.value, st.as_dict())
+
+    def upload(self, s):
+        self._config(s)
+        _chk(_ffi.lib().rth_caster_upload(s.h))
+
+    def trace(self, s, orig4, dir4):
+        """Closest hit per explicit ray (rtmi_trace): -> tri, t, face, stats."""
+        o4, d4 = _f(orig4).reshape(-1, 4), _f(dir4).reshape(-1, 4)
+        n = o4.shape[0]
+        tri, t, face = np.zeros(n, np.uint32), np.zeros(n, np.float32), np.zeros(n, np.uint32)
+        self._config(s)
+        st = _ffi.Stats()
+        _chk(_ffi.lib().rth_caster_trace(s.h, n, _p(o4), _p(d4), _p(tri), _p(t), _p(face), C.byref(st)))
+        return tri, t, face, st.as_dict()
+
+
+def quantize(rgba):
+    """write_png's `(c * 255.) as u8` (raytrace.rs:1468-1473)."""
+    rgba = _f(rgba).reshape(-1, 4)
+    out = np.zeros((rgba.shape[0], 3), np.uint8)
+    _ffi.lib().rth_quantize(_p(rgba), rgba.shape[0], _p(out))
+    return out
+
+
+# ---------------------------------------------------------------- scenes of the benchmark configs
+def canonical_scene(obj_path, accel="octree", maxdepth=10, minobjs=19, teapot_surface=None, threads=0):
+    """The scene of raytrace/src/main.rs:116-164."""
+    s = Scene(with_dummy=True)
+    tsurf = teapot_surface or SurfaceKind.Matte(make_color(252, 119, 0), 0.2)
+    s.extend_parse_obj(obj_path, [0.0, 0.5, 5.0], 1.0, create_transform(unit([0.0, 0.3, 1.0]), to_radians(270.0)), tsurf, 0.05)
+    side = SurfaceKind.Matte(make_color(40, 40, 40), 0.2)
+    s.extend_make_disk([4.0, 4.0, 7.0], unit([-0.3, -0.55, -0.5]), 2.0, 0.1, 50,
+                       SurfaceKind.Reflective(0.0002, make_color(230, 230, 230), 0.7), side, -1.0)
+    s.extend_make_disk([4.0, -3.0, 5.0], unit([-0.5, 2.0, -0.5]), 1.0, 0.04, 50,
+                       SurfaceKind.Reflective(0.002, make_color(230, 230, 230), 0.7), side, -1.0)
+    s.populate_triangle_numbers()
+    if accel == "octree":
+        s.build_bounding_box([0.0, 0.0, 20.1], 20.0, maxdepth, minobjs, threads)
+    elif accel == "trivial":
+        s.build_trivial_bounding_box([0.0, 0.0, 0.0], 20.0)
+    return s
+
+
+def canonical_viewport(w, h, maxdepth=5, samples=1):
+    """main.rs:166-173"""
+    aspect = np.float32(h) / np.float32(w)
+    return create_viewport((w, h), (1.0, float(np.float32(1.0) * aspect)), [2.0, 0.0, 0.0], unit([0.0, 0.0, 1.0]), 90.0,
+                           to_radians(0.0), maxdepth, samples)

@@ -1,0 +1,203 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import (TEAPOT, assert_bits_equal, build_pair, recipe_axis_box, recipe_canonical, recipe_circles)
+
+pytestmark = pytest.mark.gpu
+
+
+def _orc():
+    from oracle import orc
+    return orc
+
+
+def _R():
+    from rust_raytrace_amd import raytrace as R
+    return R
+
+
+def _viewports(w, h, maxdepth, spp):
+    return _orc().canonical_viewport(w, h), _R().canonical_viewport(w, h, maxdepth, spp)
+
+
+def _render_both(pair, w, h, maxdepth, spp, seed=1, options=0):
+    so, sp = pair
+    vo, vp = _viewports(w, h, maxdepth, spp)
+    assert_bits_equal(vo, vp.vp12, "viewport")
+    ref, cn = so.render(w, h, vo, maxdepth, spp, seed=seed, threads=8)
+    img = np.zeros((h, w, 4), np.float32)
+    ctx = _R().HipRayCaster(seed=seed, options=options).walk_rays(vp, sp, img, 1, False)
+    return ref, cn, img, ctx
+
+
+def _compare_hits(so, sp, o4, d4):
+    tri_o, t_o, face_o, cn = so.trace(o4, d4)
+    tri_g, t_g, face_g, st = _R().HipRayCaster(options=_R().OPT_COUNTERS).trace(sp, o4, d4)
+    bad = np.nonzero(tri_o != tri_g)[0]
+    assert len(bad) == 0, f"{len(bad)} hit ids differ, first ray {bad[:5]}: {tri_o[bad[:5]]} vs {tri_g[bad[:5]]}"
+    hit = tri_o != 0
+    assert_bits_equal(t_o[hit], t_g[hit], "hit time")
+    assert np.array_equal(face_o[hit], face_g[hit]), "face"
+    for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
+        assert st[k] == cn[k], f"work counter {k}: device {st[k]} vs oracle {cn[k]}"
+    return tri_o, cn
+
+
+def test_trace_primary_rays_canonical(canonical_pair):
+    so, sp = canonical_pair
+    vo, _ = _viewports(64, 64, 5, 1)
+    o4, d4 = _orc().primary_rays(64, 64, vo, 1)
+    tri, _ = _compare_hits(so, sp, o4, d4)
+    assert (tri != 0).sum() > 500  # the teapot is in view
+
+
+def test_trace_random_rays_canonical(canonical_pair):
+    so, sp = canonical_pair
+    rng = np.random.default_rng(7)
+    n = 20000
+    o4 = np.zeros((n, 4), np.float32)
+    d4 = np.zeros((n, 4), np.float32)
+    o4[:, :3] = rng.uniform(-6, 6, (n, 3)) + np.array([0, 0, 6])
+    d = rng.normal(size=(n, 3))
+    d4[:, :3] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    _compare_hits(so, sp, o4, d4)
+
+
+def test_trace_edge_case_rays():
+    so, sp = build_pair(recipe_axis_box())
+    rays = []
+    for ox in (-1.0, -0.5, 0.0, 0.25, 1.0):
+        for oy in (-1.0, 0.0, 0.25, 0.5):
+            for dvec in ((0, 0, 1), (0, 0, -1), (1, 0, 0), (0, 1, 0), (0, -1, 0), (-1, 0, 0), (0.6, 0, 0.8), (0, 0.6, 0.8),
+                         (-0.0, 0.0, 1.0), (1e-30, 0, 1), (0.57735026, 0.57735026, 0.57735026)):
+                rays.append(((ox, oy, 3.5, 0.0), (*dvec, 0.0)))
+                rays.append(((ox, oy, 5.0, 0.0), (*dvec, 0.0)))     # origin on the z = 5 plane
+                rays.append(((-1.0, oy, 4.0, 0.0), (*dvec, 0.0)))   # origin on the x = -1 plane
+    # poisoned rays: NaN / inf components and a NaN lane 3
+    rays += [((0, 0, 0, 0), (np.nan, 0, 1, 0)), ((np.nan, 0, 0, 0), (0, 0, 1, 0)), ((0, 0, 0, np.nan), (0, 0, 1, 0)),
+             ((0, 0, 0, 0), (0, 0, 1, np.nan)), ((np.inf, 0, 0, 0), (0, 0, 1, 0)), ((0, 0, 0, 0), (0, 0, 0, 0))]
+    o4 = np.array([r[0] for r in rays], np.float32)
+    d4 = np.array([r[1] for r in rays], np.float32)
+    _compare_hits(so, sp, o4, d4)
+
+
+def test_render_canonical_solid_spp1_is_rng_free():
+    # spp == 1 and all-Solid teapot: the reference itself is deterministic here
+    pair = build_pair(recipe_canonical(solid_teapot=True))
+    ref, cn, img, ctx = _render_both(pair, 64, 64, 5, 1)
+    assert_bits_equal(ref, img, "image")
+    assert ctx.total_rays == cn["rays"]
+
+
+def test_render_canonical_spp1(canonical_pair):
+    ref, cn, img, ctx = _render_both(canonical_pair, 64, 64, 5, 1)
+    assert_bits_equal(ref, img, "image")
+    assert ctx.total_rays == cn["rays"]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 0xDEADBEEFCAFE])
+def test_render_canonical_spp4_seeded(canonical_pair, seed):
+    ref, cn, img, ctx = _render_both(canonical_pair, 48, 32, 5, 4, seed=seed)
+    assert_bits_equal(ref, img, "image")
+    assert ctx.total_rays == cn["rays"]
+
+
+def test_render_counters_match_oracle(canonical_pair):
+    ref, cn, img, ctx = _render_both(canonical_pair, 32, 32, 5, 2, options=_R().OPT_COUNTERS)
+    assert_bits_equal(ref, img, "image")
+    for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
+        assert ctx.stats[k] == cn[k], k
+
+
+@pytest.mark.parametrize("maxdepth", [0, 1, 2, 8])
+def test_render_depth_limits(canonical_pair, maxdepth):
+    ref, cn, img, ctx = _render_both(canonical_pair, 32, 32, maxdepth, 2)
+    assert_bits_equal(ref, img, "image")
+    assert ctx.total_rays == cn["rays"]
+
+
+def test_render_circles_config1(circles_pair):
+    # BASELINE config 1: 256x256, 1 spp (plumbing)
+    ref, cn, img, ctx = _render_both(circles_pair, 256, 256, 5, 1)
+    assert_bits_equal(ref, img, "image")
+    assert ctx.total_rays == cn["rays"]
+
+
+def test_render_circles_seeded(circles_pair):
+    ref, cn, img, ctx = _render_both(circles_pair, 64, 64, 5, 8, seed=5)
+    assert_bits_equal(ref, img, "image")
+
+
+def test_render_linear_list_config2_small():
+    # BASELINE config 2 shape: teapot.obj, trivial bounding box (one leaf = linear list), reduced size
+    pair = build_pair(recipe_canonical(accel="trivial", obj=TEAPOT))
+    ref, cn, img, ctx = _render_both(pair, 32, 32, 5, 2)
+    assert_bits_equal(ref, img, "image")
+    assert ctx.total_rays == cn["rays"]
+
+
+def test_render_axis_aligned_scene():
+    pair = build_pair(recipe_axis_box())
+    so, sp = pair
+    orc, R = _orc(), _R()
+    # camera looking straight down +z through the box: many rays parallel to walls
+    w = h = 33  # odd: the centre column has dir.x == 0 exactly
+    vo = orc.create_viewport(w, h, (1.0, 1.0), [0.0, 0.0, 0.0], orc.unit([0.0, 0.0, 1.0]), 90.0, 0.0)
+    vp = R.create_viewport((w, h), (1.0, 1.0), [0.0, 0.0, 0.0], R.unit([0.0, 0.0, 1.0]), 90.0, 0.0, 5, 1)
+    assert_bits_equal(vo, vp.vp12, "viewport")
+    ref, cn = so.render(w, h, vo, 5, 1)
+    img = np.zeros((h, w, 4), np.float32)
+    R.HipRayCaster().walk_rays(vp, sp, img, 1, False)
+    assert_bits_equal(ref, img, "image")
+
+
+def test_row_partition_invariance(canonical_pair):
+    so, sp = canonical_pair
+    R = _R()
+    vp = R.canonical_viewport(40, 40, 5, 3)
+    whole = np.zeros((40, 40, 4), np.float32)
+    c = R.HipRayCaster(seed=9)
+    total = c.walk_rays(vp, sp, whole, 1, False).total_rays
+    parts = np.zeros_like(whole)
+    rays = 0
+    for row0, n in ((0, 7), (7, 20), (27, 13)):
+        rays += c.walk_rows(vp, sp, row0, n, parts[row0:row0 + n]).total_rays
+    assert_bits_equal(whole, parts, "row tiles")
+    assert rays == total
+    empty = np.zeros((0, 40, 4), np.float32)
+    assert c.walk_rows(vp, sp, 5, 0, empty).total_rays == 0
+
+
+def test_small_batches_same_image(canonical_pair, monkeypatch):
+    so, sp = canonical_pair
+    R = _R()
+    vp = R.canonical_viewport(32, 32, 5, 4)
+    a = np.zeros((32, 32, 4), np.float32)
+    R.HipRayCaster(seed=3).walk_rays(vp, sp, a, 1, False)
+    monkeypatch.setenv("RTMI_BATCH_PATHS", "1000")  # forces many ragged batches
+    b = np.zeros_like(a)
+    R.HipRayCaster(seed=3).walk_rays(vp, sp, b, 1, False)
+    assert_bits_equal(a, b, "batched")
+
+
+def test_quantize_matches_oracle(canonical_pair):
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-0.2, 1.2, (1000, 4)).astype(np.float32)
+    x[0] = [np.nan, np.inf, -np.inf, 0]
+    x[1] = [1.0, 0.999999, 0.0, 0]
+    assert np.array_equal(_orc().quantize(x), _R().quantize(x))
+
+
+def test_error_behaviour(canonical_pair):
+    so, sp = canonical_pair
+    R = _R()
+    vp = R.canonical_viewport(16, 16, 5, 0)  # spp 0
+    with pytest.raises(RuntimeError):
+        R.HipRayCaster().walk_rays(vp, sp, np.zeros((16, 16, 4), np.float32), 1, False)
+    vp = R.canonical_viewport(16, 16, 5, 1)
+    with pytest.raises(RuntimeError):
+        R.HipRayCaster().walk_rows(vp, sp, 10, 10, np.zeros((10, 16, 4), np.float32))  # rows outside the image
+    empty = R.Scene()
+    with pytest.raises(RuntimeError):
+        R.HipRayCaster().walk_rays(vp, empty, np.zeros((16, 16, 4), np.float32), 1, False)  # no bounding box
