@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s and s/frame, teapot_tri.obj 2048x2048 @ 64 spp (BASELINE.json config 3).
+
+A step = one frame of the canonical scene (raytrace/src/main.rs:116-173: teapot_tri.obj + two mirror
+disks, octree (maxdepth 10, minobjs 19), depth 5) through HipRayCaster.  With N > 1 ranks the frame is
+tiled by interleaved row stripes, one rank per GPU, and collected by ONE gather (RCCL) on rank 0 inside
+the timed region; the total work is fixed, so scaling is "strong".  Rays = project_ray calls with
+depth > 0 (raytrace.rs:1278), the reference's "Rays" statistic.
+
+Prints one JSON line (rank 0).  Extra legs outside the timed region: a counting pass (device work
+counters -> algorithmic bytes for the roofline) and the CPU baseline (the oracle on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--height", type=int, default=2048)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--maxdepth", type=int, default=5)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--stripe-rows", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-counters", action="store_true")
+    ap.add_argument("--cpu-sample", default="256x256x8", help="WxHxSPP of the CPU baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from rust_raytrace_amd import dist as rdist
+    from rust_raytrace_amd import raytrace as R
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    obj = os.path.join(ROOT, "tests", "golden", "teapot_tri.obj")
+    t0 = time.time()
+    scene = R.canonical_scene(obj)  # octree (10, 19)
+    t_build = time.time() - t0
+    W, H, spp = args.width, args.height, args.spp
+    vp = R.canonical_viewport(W, H, args.maxdepth, spp)
+    caster = R.HipRayCaster(seed=args.seed, device=local_rank)
+    t0 = time.time()
+    caster.upload(scene)
+    t_upload = time.time() - t0
+
+    tile = rdist.rank_tile(rank, world, H, args.stripe_rows)
+    local = torch.zeros((tile[1], W, 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def step():
+        ctx = caster.walk_tile_device(vp, scene, tile, local.data_ptr(), stream.cuda_stream)
+        frame = rdist.gather_frame(local, rank, world, H, W, args.stripe_rows)
+        return ctx, frame
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    rays = 0
+    trace_ms = 0.0
+    kernel_ms = 0.0
+    launches = 0
+    frame = None
+    for _ in range(args.steps):
+        ctx, frame = step()
+        rays += ctx.total_rays
+        trace_ms += ctx.stats["trace_ms"]
+        kernel_ms += ctx.stats["kernel_ms"]
+        launches += ctx.stats["trace_launches"]
+    barrier()
+    dt = time.perf_counter() - t0
+
+    tot = torch.tensor([float(rays), dt, trace_ms, kernel_ms, float(launches)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt = float(mx[1])
+        rays = float(sm[0])
+    else:
+        rays = float(tot[0])
+
+    # ---- legs outside the timed region (rank 0 of a 1-GPU run only)
+    roofline = None
+    cpu_baseline = None
+    if rank == 0:
+        alg_bytes = None
+        if world == 1 and not args.no_counters:
+            # device work counters of one full frame -> algorithmic bytes:
+            # 16 B per box test + 4 B per leaf reference + 28 B per triangle test (plane part)
+            # + 52 B per test that passes the bounding-radius check (edge part)
+            caster.options = R.OPT_COUNTERS
+            cctx = caster.walk_tile_device(vp, scene, tile, local.data_ptr(), stream.cuda_stream)
+            caster.options = 0
+            st = cctx.stats
+            alg_bytes = 16 * st["box_tests"] + 4 * st["tri_tests"] + 28 * st["tri_tests"] + 52 * st["full_tests"]
+            per_launch_bytes = alg_bytes / max(st["trace_launches"], 1)
+            avg_launch_ms = trace_ms / max(launches, 1)
+            achieved = per_launch_bytes / (avg_launch_ms * 1e-3) / 1e9
+            traffic = None
+            pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pj):
+                try:
+                    traffic = json.load(open(pj)).get("k_trace_hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(avg_launch_ms, 3),
+                        "bytes_per_ray": round(alg_bytes / max(st["rays"], 1), 1),
+                        "trace_share_of_kernel_time": round(trace_ms / max(kernel_ms, 1e-9), 3),
+                        "note": "served from L2/Infinity Cache (scene ~19 MB); VALU/latency-bound, see DESIGN.md"}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import orc
+            cw, ch, cspp = (int(x) for x in args.cpu_sample.split("x"))
+            so = orc.canonical_scene(obj)
+            vo = orc.canonical_viewport(cw, ch)
+            cores = len(os.sched_getaffinity(0))
+            t1 = time.perf_counter()
+            _, cn = so.render(cw, ch, vo, args.maxdepth, cspp, seed=args.seed, threads=cores)
+            cdt = time.perf_counter() - t1
+            cpu_baseline = {"value": round(cn["rays"] / cdt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                            "sample": f"canonical scene, same camera, {cw}x{ch} @ {cspp} spp, depth {args.maxdepth}: "
+                                      f"{cn['rays']} rays in {cdt:.2f} s wall"}
+
+        value = rays / dt / 1e6
+        out = {
+            "metric": "Mrays/s, teapot_tri.obj 2048x2048 @64spp (primary + bounce rays per second of frame time)",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "s_per_frame": round(dt / args.steps, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"canonical main.rs scene (teapot_tri.obj + 2 mirror disks, 6721 triangles), octree (10,19), "
+                                   f"{W}x{H} @ {spp} spp, depth {args.maxdepth}, seed {args.seed}",
+                       "tiling": f"{world} x interleaved {args.stripe_rows}-row stripes + one gather", "rays_per_frame": int(rays / args.steps)},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "setup": {"octree_build_s": round(t_build, 2), "scene_upload_s": round(t_upload, 3)},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

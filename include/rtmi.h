@@ -83,6 +83,15 @@ typedef struct rtmi_stats {
     uint32_t reserved;
 } rtmi_stats_t;
 
+/* A set of image rows: `nrows` rows taken in stripes of `stripe_rows`
+ * consecutive rows, the k-th stripe starting at row0 + k*stripe_step.
+ * {row0, nrows, nrows, 0} is the contiguous band [row0, row0+nrows).
+ * Interleaved stripes are how a frame is tiled over the GPUs of a node: rank r
+ * of N takes {r*S, H/N, S, N*S}; cost per row is very uneven (sky vs teapot). */
+typedef struct rtmi_tile {
+    uint32_t row0, nrows, stripe_rows, stripe_step;
+} rtmi_tile_t;
+
 typedef struct rtmi_scene rtmi_scene_t;
 
 /* Number of visible HIP devices (0 when none); never fails. */
@@ -118,6 +127,10 @@ int rtmi_render(rtmi_scene_t* scene, const rtmi_viewport_t* vp, uint64_t seed,
 int rtmi_render_device(rtmi_scene_t* scene, const rtmi_viewport_t* vp, uint64_t seed,
                        uint32_t row0, uint32_t nrows, void* out_device, void* hip_stream,
                        rtmi_stats_t* stats);
+/* Same for a striped row set; output row i is the i-th row of the tile. */
+int rtmi_render_tile_device(rtmi_scene_t* scene, const rtmi_viewport_t* vp, uint64_t seed,
+                            const rtmi_tile_t* tile, void* out_device, void* hip_stream,
+                            rtmi_stats_t* stats);
 
 /* Closest hit for n explicit rays: orig (x,y,z,lane3) and unit dir
  * (x,y,z,lane3) as `make_ray` stores them (raytrace.rs:201-210).  Outputs per

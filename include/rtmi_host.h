@@ -64,6 +64,9 @@ int rth_caster_walk_rows(rth_scene_t* s, uint32_t w, uint32_t h, const float* vp
 int rth_caster_walk_rows_device(rth_scene_t* s, uint32_t w, uint32_t h, const float* vp12, uint64_t maxdepth, uint64_t spp,
                                 uint64_t row0, uint64_t nrows, void* out_device, void* hip_stream, rtmi_stats_t* stats,
                                 double* wall_seconds);
+int rth_caster_walk_tile_device(rth_scene_t* s, uint32_t w, uint32_t h, const float* vp12, uint64_t maxdepth, uint64_t spp,
+                                const rtmi_tile_t* tile, void* out_device, void* hip_stream, rtmi_stats_t* stats,
+                                double* wall_seconds);
 int rth_caster_trace(rth_scene_t* s, uint64_t n, const float* orig4, const float* dir4, uint32_t* tri, float* t,
                      uint32_t* face, rtmi_stats_t* stats);
 int rth_caster_upload(rth_scene_t* s); /* make the scene resident now (otherwise on first use) */

@@ -23,6 +23,11 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
 
 
+class Tile(C.Structure):
+    """rtmi_tile_t (include/rtmi.h)."""
+    _fields_ = [("row0", C.c_uint32), ("nrows", C.c_uint32), ("stripe_rows", C.c_uint32), ("stripe_step", C.c_uint32)]
+
+
 def build(force=False):
     """Compile librtmi.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     if force:
@@ -42,6 +47,14 @@ def lib():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C rust_raytrace_amd/csrc). There is no CPU fallback for the render path.")
+    # One HIP runtime per process: torch bundles its own libamdhip64 (SONAME libamdhip64.so.7) and
+    # librtmi.so needs that SONAME, so with torch loaded FIRST both share torch's runtime (streams and
+    # device pointers are then interchangeable).  Loaded the other way round the process ends up with
+    # two runtimes and torch sees no GPU.  Without torch the system /opt/rocm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u64, u32, f32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_float, C.c_int
     L.rtmi_last_error.restype = C.c_char_p
@@ -74,6 +87,7 @@ def lib():
     L.rth_caster_upload.argtypes = [vp]
     L.rth_caster_walk_rows.argtypes = [vp, u32, u32, vp, u64, u64, u64, u64, vp, vp, vp]
     L.rth_caster_walk_rows_device.argtypes = [vp, u32, u32, vp, u64, u64, u64, u64, vp, vp, vp, vp]
+    L.rth_caster_walk_tile_device.argtypes = [vp, u32, u32, vp, u64, u64, vp, vp, vp, vp, vp]
     L.rth_caster_trace.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
     L.rth_quantize.argtypes = [vp, u64, vp]
     _lib = L
@@ -82,10 +96,10 @@ def lib():
 
 # every symbol include/rtmi.h and include/rtmi_host.h declare
 RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_set_options", "rtmi_render",
-                "rtmi_render_device", "rtmi_trace", "rtmi_quantize", "rtmi_last_error"]
+                "rtmi_render_device", "rtmi_render_tile_device", "rtmi_trace", "rtmi_quantize", "rtmi_last_error"]
 RTH_SYMBOLS = ["rth_last_error", "rth_make_color", "rth_unit", "rth_to_radians", "rth_create_transform",
                "rth_create_viewport", "rth_scene_new", "rth_scene_free", "rth_num_tris", "rth_add_triangle", "rth_add_obj",
                "rth_add_disk", "rth_add_sphere", "rth_populate_triangle_numbers", "rth_build_bounding_box",
                "rth_build_trivial_bounding_box", "rth_box_contains_polygon", "rth_face_contains_triangle",
                "rth_get_triangles", "rth_tree_sizes", "rth_tree_get", "rth_caster_config", "rth_caster_walk_rows",
-               "rth_caster_walk_rows_device", "rth_caster_trace", "rth_caster_upload", "rth_quantize"]
+               "rth_caster_walk_rows_device", "rth_caster_walk_tile_device", "rth_caster_trace", "rth_caster_upload", "rth_quantize"]

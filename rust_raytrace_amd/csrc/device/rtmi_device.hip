@@ -61,7 +61,16 @@ struct DScene {
 struct DView {
     V4 orig, cam, vu, vv;
     uint32_t width, height, maxdepth, spp;
+    uint32_t row0, stripe_rows, stripe_step, pad;  // rtmi_tile_t: which image rows the local rows are
 };
+
+// local pixel index of the tile (row-major over the tile's rows) -> image (row, col)
+__device__ inline void tile_pixel(const DView& v, uint32_t lp, uint32_t& row, uint32_t& col) {
+    const uint32_t lr = lp / v.width;
+    col = lp - lr * v.width;
+    const uint32_t k = lr / v.stripe_rows;
+    row = v.row0 + k * v.stripe_step + (lr - k * v.stripe_rows);
+}
 
 #define RTMI_MAX_PASSES 32
 struct DCtrl {
@@ -340,8 +349,10 @@ __global__ void __launch_bounds__(256) k_gen(DView v, uint64_t seed, uint32_t pi
                                              uint32_t* __restrict__ qpath, DCtrl* __restrict__ ctrl) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t path = blockIdx.x * blockDim.x + threadIdx.x; path < npaths; path += stride) {
-        const uint32_t pixel = pix0 + path / v.spp, sample = path % v.spp;
-        const uint32_t row = pixel / v.width, col = pixel % v.width;
+        const uint32_t lp = pix0 + path / v.spp, sample = path % v.spp;
+        uint32_t row, col;
+        tile_pixel(v, lp, row, col);
+        const uint32_t pixel = row * v.width + col;
         RayV r = pixel_ray(v, row, col, seed, pixel, sample);
         qo[path] = make_float4(r.orig.x, r.orig.y, r.orig.z, r.orig.w);
         qd[path] = make_float4(r.dir.x, r.dir.y, r.dir.z, r.dir.w);
@@ -381,7 +392,10 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed
             path = qpath[i];
             const uint32_t tf = hit_tf[i];
             const uint32_t tri = tf & 0x3FFFFFFFu, face = tf >> 30;
-            const uint32_t pixel = pix0 + path / v.spp, sample = path % v.spp;
+            const uint32_t sample = path % v.spp;
+            uint32_t prow, pcol;
+            tile_pixel(v, pix0 + path / v.spp, prow, pcol);
+            const uint32_t pixel = prow * v.width + pcol;
             V4 c;
             uint32_t npushed = (uint32_t)pass;
             if (tri == 0) {
@@ -722,9 +736,25 @@ static int read_stats(rtmi_scene* s, hipStream_t st, rtmi_stats_t* stats, float 
 
 int rtmi_render_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t seed, uint32_t row0, uint32_t nrows,
                        void* out_device, void* hip_stream, rtmi_stats_t* stats) {
-    if (!s || !vp || !out_device) return fail(RTMI_ERR_INVALID, "NULL argument");
+    const rtmi_tile_t tile{row0, nrows, nrows ? nrows : 1u, 0u};
+    return rtmi_render_tile_device(s, vp, seed, &tile, out_device, hip_stream, stats);
+}
+
+int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t seed, const rtmi_tile_t* tile,
+                            void* out_device, void* hip_stream, rtmi_stats_t* stats) {
+    if (!s || !vp || !tile) return fail(RTMI_ERR_INVALID, "NULL argument");
+    const uint32_t row0 = tile->row0, nrows = tile->nrows;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (nrows == 0) return RTMI_OK;
+    if (!out_device) return fail(RTMI_ERR_INVALID, "NULL argument");
     if (vp->width == 0 || vp->height == 0) return fail(RTMI_ERR_INVALID, "empty viewport");
-    if ((uint64_t)row0 + nrows > vp->height) return fail(RTMI_ERR_INVALID, "row range outside the viewport");
+    if (tile->stripe_rows == 0) return fail(RTMI_ERR_INVALID, "stripe_rows must be >= 1");
+    {
+        const uint64_t nstripes = ((uint64_t)nrows + tile->stripe_rows - 1) / tile->stripe_rows;
+        const uint64_t last_row = (uint64_t)row0 + (nstripes - 1) * tile->stripe_step + ((uint64_t)nrows - 1 - (nstripes - 1) * tile->stripe_rows);
+        if (last_row >= vp->height) return fail(RTMI_ERR_INVALID, "row range outside the viewport");
+        if (nstripes > 1 && tile->stripe_step < tile->stripe_rows) return fail(RTMI_ERR_INVALID, "stripes overlap");
+    }
     if (vp->samples_per_pixel == 0) return fail(RTMI_ERR_INVALID, "samples_per_pixel must be >= 1");  // reference: 1/0 -> NaN image
     if (vp->maxdepth > RTMI_MAX_PASSES) return fail(RTMI_ERR_UNSUPPORTED, "maxdepth above 32");
     if ((uint64_t)vp->width * vp->height >= (1ull << 32)) return fail(RTMI_ERR_UNSUPPORTED, "more than 2^32 pixels");
@@ -733,8 +763,6 @@ int rtmi_render_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t seed
     const uint32_t W = vp->width, spp = vp->samples_per_pixel, maxdepth = vp->maxdepth;
     const uint64_t npix = (uint64_t)nrows * W;
     float4* out = (float4*)out_device;
-    if (stats) memset(stats, 0, sizeof(*stats));
-    if (npix == 0) return RTMI_OK;
     if (maxdepth == 0) {  // project_ray returns black immediately (raytrace.rs:1261-1263); acc*(1/spp) of zeros
         HIPCHK(hipMemsetAsync(out, 0, npix * sizeof(float4), st));
         HIPCHK(hipStreamSynchronize(st));
@@ -754,6 +782,7 @@ int rtmi_render_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t seed
     dv.vu = mk(vp->vu[0], vp->vu[1], vp->vu[2]);
     dv.vv = mk(vp->vv[0], vp->vv[1], vp->vv[2]);
     dv.width = W; dv.height = vp->height; dv.maxdepth = maxdepth; dv.spp = spp;
+    dv.row0 = row0; dv.stripe_rows = tile->stripe_rows; dv.stripe_step = tile->stripe_step; dv.pad = 0;
 
     const bool counting = (s->options & RTMI_OPT_COUNTERS) != 0;
     const unsigned ew_blocks = (unsigned)(s->num_cu * 8);
@@ -767,7 +796,7 @@ int rtmi_render_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t seed
     for (uint64_t p0 = 0; p0 < npix; p0 += pix_per_batch) {
         const uint32_t np = (uint32_t)std::min<uint64_t>(pix_per_batch, npix - p0);
         const uint32_t npaths = np * spp;
-        const uint32_t pix0 = (uint32_t)((uint64_t)row0 * W + p0);
+        const uint32_t pix0 = (uint32_t)p0;  // local pixel index inside the tile
         HIPCHK(hipMemsetAsync(s->ctrl.p, 0, sizeof(DCtrl), st));
         HIPCHK(hipEventRecord(s->ev[0], st));
         hipLaunchKernelGGL(k_gen, dim3(ew_blocks), dim3(256), 0, st, dv, seed, pix0, npaths, s->qo[0].p, s->qd[0].p, s->qpath[0].p, s->ctrl.p);

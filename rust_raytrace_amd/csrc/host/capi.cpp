@@ -171,6 +171,17 @@ int rth_caster_walk_rows_device(rth_scene_t* s, uint32_t w, uint32_t h, const fl
         if (stats) *stats = ctx.stats;
     });
 }
+int rth_caster_walk_tile_device(rth_scene_t* s, uint32_t w, uint32_t h, const float* vp12, uint64_t maxdepth, uint64_t spp,
+                                const rtmi_tile_t* tile, void* out_device, void* hip_stream, rtmi_stats_t* stats, double* wall) {
+    return guarded([&] {
+        const Viewport v = vp_from(w, h, vp12, maxdepth, spp);
+        ProgressCtx ctx;
+        const auto t0 = std::chrono::steady_clock::now();
+        caster_of(s).walk_tile_device(v, s->scene, *tile, out_device, hip_stream, ctx);
+        if (wall) *wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (stats) *stats = ctx.stats;
+    });
+}
 int rth_caster_trace(rth_scene_t* s, uint64_t n, const float* o4, const float* d4, uint32_t* tri, float* t, uint32_t* face,
                      rtmi_stats_t* stats) {
     return guarded([&] {

@@ -487,11 +487,17 @@ rtmi_scene_t* HipRayCaster::resident(const Scene& s) {
 
 void HipRayCaster::walk_rows_device(const Viewport& v, const Scene& s, size_t row0, size_t nrows, void* out_device,
                                     void* hip_stream, ProgressCtx& progress) {
+    const rtmi_tile_t tile{(uint32_t)row0, (uint32_t)nrows, nrows ? (uint32_t)nrows : 1u, 0u};
+    walk_tile_device(v, s, tile, out_device, hip_stream, progress);
+}
+
+void HipRayCaster::walk_tile_device(const Viewport& v, const Scene& s, const rtmi_tile_t& tile, void* out_device,
+                                    void* hip_stream, ProgressCtx& progress) {
     rtmi_scene_t* h = resident(s);
     const rtmi_viewport_t av = to_abi(v);
     rtmi_stats_t st;
-    const int rc = rtmi_render_device(h, &av, seed, (uint32_t)row0, (uint32_t)nrows, out_device, hip_stream, &st);
-    if (rc != RTMI_OK) throw std::runtime_error(std::string("rtmi_render_device: ") + rtmi_last_error());
+    const int rc = rtmi_render_tile_device(h, &av, seed, &tile, out_device, hip_stream, &st);
+    if (rc != RTMI_OK) throw std::runtime_error(std::string("rtmi_render_tile_device: ") + rtmi_last_error());
     progress.total_rays += st.rays;
     progress.kernel_seconds += st.kernel_ms * 1e-3;
     progress.stats = st;

@@ -146,6 +146,9 @@ public:
     void walk_rows(const Viewport& v, const Scene& s, size_t row0, size_t nrows, Color* data, ProgressCtx& progress);
     void walk_rows_device(const Viewport& v, const Scene& s, size_t row0, size_t nrows, void* out_device,
                           void* hip_stream, ProgressCtx& progress);
+    // Striped row set (rtmi_tile_t): rank r of N renders {r*S, H/N, S, N*S}.
+    void walk_tile_device(const Viewport& v, const Scene& s, const rtmi_tile_t& tile, void* out_device,
+                          void* hip_stream, ProgressCtx& progress);
     void set_options(uint32_t opts) { options_ = opts; }
     rtmi_scene_t* resident(const Scene& s);  // uploads on first use / when the scene changed
     void invalidate();

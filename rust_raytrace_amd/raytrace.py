@@ -217,6 +217,17 @@ class HipRayCaster:
                                                     C.byref(st), C.byref(wall)))
         return ProgressCtx(st.rays, wall.value, st.as_dict())
 
+    def walk_tile_device(self, v, s, tile, out_ptr, stream_ptr=None):
+        """Striped row set: tile = (row0, nrows, stripe_rows, stripe_step) — rtmi_tile_t."""
+        self._config(s)
+        st = _ffi.Stats()
+        wall = C.c_double(0)
+        t = _ffi.Tile(*[int(x) for x in tile])
+        _chk(_ffi.lib().rth_caster_walk_tile_device(s.h, v.width, v.height, _p(v.vp12), v.maxdepth, v.samples_per_pixel,
+                                                    C.byref(t), C.c_void_p(out_ptr), C.c_void_p(stream_ptr or 0),
+                                                    C.byref(st), C.byref(wall)))
+        return ProgressCtx(st.rays, wall.value, st.as_dict())
+
     def upload(self, s):
         self._config(s)
         _chk(_ffi.lib().rth_caster_upload(s.h))

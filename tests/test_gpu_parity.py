@@ -201,3 +201,26 @@ def test_error_behaviour(canonical_pair):
     empty = R.Scene()
     with pytest.raises(RuntimeError):
         R.HipRayCaster().walk_rays(vp, empty, np.zeros((16, 16, 4), np.float32), 1, False)  # no bounding box
+
+
+def test_striped_tiles_equal_whole_image(canonical_pair):
+    import torch
+    from rust_raytrace_amd import dist as rd
+    so, sp = canonical_pair
+    R = _R()
+    H, W = 40, 24
+    vp = R.canonical_viewport(W, H, 5, 2)
+    whole = np.zeros((H, W, 4), np.float32)
+    c = R.HipRayCaster(seed=4)
+    total = c.walk_rays(vp, sp, whole, 1, False).total_rays
+    for world, S in ((2, 4), (3, 8), (8, 2)):
+        frame = np.zeros_like(whole)
+        rays = 0
+        for r in range(world):
+            tile = rd.rank_tile(r, world, H, S)
+            buf = torch.zeros((tile[1], W, 4), dtype=torch.float32, device="cuda:0")
+            rays += c.walk_tile_device(vp, sp, tile, buf.data_ptr(), torch.cuda.current_stream().cuda_stream).total_rays
+            torch.cuda.synchronize()
+            frame[rd.tile_rows(tile, H)] = buf.cpu().numpy()
+        assert_bits_equal(whole, frame, f"world {world} stripes {S}")
+        assert rays == total
