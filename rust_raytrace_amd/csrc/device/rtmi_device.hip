@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -56,6 +57,11 @@ struct DScene {
     const float4* tedge;
     const float4* mats;
     uint32_t nnodes, ntris, nmats, levels;
+    // exact-octree form (trace_oct.hpp); null when the tree is not an exact octree
+    const float4* onodes;
+    const uint4* oblocks;
+    float root_half;
+    uint32_t olevels;
 };
 
 struct DView {
@@ -321,6 +327,10 @@ __global__ void __launch_bounds__(256) k_trace(DScene sc, const float4* __restri
     }
 }
 
+}  // namespace rtmi
+#include "trace_oct.hpp"
+namespace rtmi {
+
 // ---------------------------------------------------------------- generation / shading
 struct RayV { V4 orig, dir; };
 // make_ray (raytrace.rs:201-210); inv_dir is recomputed by the trace kernel
@@ -531,7 +541,12 @@ struct rtmi_scene {
     DScene d{};
     DevBuf<DNode> nodes;
     DevBuf<uint32_t> refs;
-    DevBuf<float4> tplane, tedge, mats;
+    DevBuf<float4> tplane, tedge, mats, onodes;
+    DevBuf<uint4> oblocks;
+    bool octree = false;       // the tree passed the exact-octree check
+    std::string why_generic;   // reason when it did not
+    int oct_blocks_per_cu = 8;
+    size_t oct_lds = 0;
     // per-batch workspace
     size_t cap = 0;
     uint32_t cap_depth = 0;
@@ -609,6 +624,61 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
         const rtmi_box_t& b = boxes[i];
         hn[i] = DNode{b.orig[0], b.orig[1], b.orig[2], b.len2, b.first, b.count, b.is_leaf ? 1u : 0u, 0u};
     }
+    // ---- exact-octree form: every child must be the builder's octant of its parent, bit for bit
+    //      (orig + (+-newlen2), newlen2 = len2 / 2, raytrace.rs:816-824), stored in octant order.
+    std::vector<float4> hon;
+    std::vector<uint4> hob;
+    std::string why;
+    {
+        auto fb = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+        bool ok = nboxes < (1ull << 24);
+        if (!ok) why = "more than 2^24 boxes";
+        std::vector<uint32_t> link(nboxes, 0);
+        const float root_len2 = boxes[0].len2;
+        for (uint64_t i = 0; i < nboxes && ok; i++) {
+            const rtmi_box_t& b = boxes[i];
+            if (fb(b.len2) != fb(ldexpf(root_len2, -(int)depth[i])) || !(b.len2 > 0.f) || !std::isfinite(b.len2)) { ok = false; why = "box half-length is not root/2^depth"; break; }
+            if (b.is_leaf) {
+                for (uint32_t k = 0; k < b.count; k++)
+                    if (tri_refs[b.first + k] == 0) { ok = false; why = "a leaf lists the sentinel triangle 0"; }
+                if (!ok) break;
+                if (hob.size() >= (1ull << 24)) { ok = false; why = "more than 2^24 reference blocks"; break; }
+                link[i] = (uint32_t)hob.size();
+                for (uint32_t k = 0; k < b.count + 1; k += 4) {  // count refs + at least one terminating 0
+                    uint32_t v[4] = {0, 0, 0, 0};
+                    for (uint32_t j = 0; j < 4; j++)
+                        if (k + j < b.count) v[j] = tri_refs[b.first + k + j];
+                    hob.push_back(make_uint4(v[0], v[1], v[2], v[3]));
+                }
+            } else {
+                const float h = b.len2 / 2.f;
+                uint32_t mask = 0;
+                int prev = -1;
+                for (uint32_t k = 0; k < b.count && ok; k++) {
+                    const rtmi_box_t& c = boxes[b.first + k];
+                    int oct = 0;
+                    for (int a = 0; a < 3; a++) {
+                        const float lo = b.orig[a] + (-1.f * h), hi = b.orig[a] + h;
+                        if (fb(lo) == fb(hi)) { ok = false; why = "degenerate box"; break; }
+                        if (fb(c.orig[a]) == fb(hi)) oct |= 1 << a;
+                        else if (fb(c.orig[a]) != fb(lo)) { ok = false; why = "child centre is not an octant centre of its parent"; break; }
+                    }
+                    if (ok && oct <= prev) { ok = false; why = "children are not in octant order"; }
+                    prev = oct;
+                    mask |= 1u << oct;
+                }
+                link[i] = b.first | (mask << 24);
+            }
+        }
+        if (ok) {
+            hon.resize(nboxes);
+            for (uint64_t i = 0; i < nboxes; i++) {
+                float lf; memcpy(&lf, &link[i], 4);
+                hon[i] = make_float4(boxes[i].orig[0], boxes[i].orig[1], boxes[i].orig[2], lf);
+            }
+        } else { hon.clear(); hob.clear(); }
+    }
+
     std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t> matmap;
     std::vector<float4> hm, hp(2 * ntris), he(4 * ntris);
     auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
@@ -660,6 +730,10 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     if (e == hipSuccess) e = up(s->tplane, hp);
     if (e == hipSuccess) e = up(s->tedge, he);
     if (e == hipSuccess) e = up(s->mats, hm);
+    s->octree = !hon.empty();
+    s->why_generic = why;
+    if (e == hipSuccess && s->octree) e = up(s->onodes, hon);
+    if (e == hipSuccess && s->octree) e = up(s->oblocks, hob);
     if (e == hipSuccess) e = s->ctrl.ensure(1);
     for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&s->ev[k]);
     if (e != hipSuccess) {
@@ -668,7 +742,17 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
         return fail(e == hipErrorOutOfMemory ? RTMI_ERR_OOM : RTMI_ERR_NO_DEVICE, msg);
     }
     s->d = DScene{s->nodes.p, s->refs.p, s->tplane.p, s->tedge.p, s->mats.p,
-                  (uint32_t)nboxes, (uint32_t)ntris, (uint32_t)matmap.size(), levels};
+                  (uint32_t)nboxes, (uint32_t)ntris, (uint32_t)matmap.size(), levels,
+                  s->octree ? s->onodes.p : nullptr, s->octree ? s->oblocks.p : nullptr, boxes[0].len2, max_inner_depth + 1};
+    if (s->octree) {
+        s->oct_lds = (size_t)(max_inner_depth + 1) * 16 * 64;
+        if (s->oct_lds > 64 * 1024) { s->octree = false; s->why_generic = "octree deeper than the LDS stack allows"; }
+        else {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_oct<false>, 64, s->oct_lds) == hipSuccess && nb > 0)
+                s->oct_blocks_per_cu = nb;
+        }
+    }
     *out = s;
     return RTMI_OK;
 }
@@ -677,6 +761,7 @@ int rtmi_scene_destroy(rtmi_scene_t* s) {
     if (!s) return RTMI_OK;
     (void)hipSetDevice(s->device);
     s->nodes.release(); s->refs.release(); s->tplane.release(); s->tedge.release(); s->mats.release();
+    s->onodes.release(); s->oblocks.release();
     for (int k = 0; k < 2; k++) { s->qo[k].release(); s->qd[k].release(); s->qpath[k].release(); }
     s->scol.release(); s->tile.release(); s->hit_tf.release(); s->hit_t.release(); s->mstack.release();
     s->ctrl.release(); s->qbytes.release();
@@ -713,6 +798,12 @@ static int ensure_workspace(rtmi_scene* s, size_t cap, uint32_t maxdepth) {
 extern "C++" {
 template <bool COUNT>
 static void launch_trace(rtmi_scene* s, hipStream_t st, const float4* qo, const float4* qd, int pass) {
+    if (s->octree && !(s->options & RTMI_OPT_GENERIC)) {
+        dim3 grid((unsigned)(s->num_cu * s->oct_blocks_per_cu)), block(64);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT>), grid, block, s->oct_lds, st, s->d, qo, qd, s->ctrl.p, pass,
+                           s->hit_tf.p, s->hit_t.p);
+        return;
+    }
     // persistent grid: enough blocks to fill every CU at the occupancy LDS allows
     const int per_cu = s->trace_block == 256 ? 4 : 16;
     dim3 grid((unsigned)(s->num_cu * per_cu)), block((unsigned)s->trace_block);

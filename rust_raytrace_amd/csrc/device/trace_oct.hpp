@@ -1,0 +1,270 @@
+// trace_oct.hpp — the closest-hit kernel for trees that are exact octrees
+// (what build_bounding_box produces, raytrace_lib/src/raytrace.rs:795-845;
+// checked box by box in rtmi_scene_create, otherwise the generic kernel of
+// rtmi_device.hip runs).  Included by rtmi_device.hip.
+//
+// Same traversal order and skip rule as get_object_intersection_for_ray
+// (raytrace.rs:909-1010), restructured for a 64-lane wavefront:
+//
+//  * one lane = one ray, lanes are PERSISTENT: a lane that finishes pulls the
+//    next queued ray (wave ballot + prefix sum over the idle lanes, one atomic
+//    per refill), so a wave stays full until the queue is empty;
+//  * a lane is in one of two working states, SELECT (at a box: pop finished
+//    frames, pick the next child in sorted order, apply the skip rule, expand
+//    it or enter it as a leaf) or LEAF (scan one 16-B block of triangle
+//    references).  Each iteration the wave runs the step that the majority of
+//    its lanes wait for, instead of serialising nested per-lane loops;
+//  * child boxes are implicit: the 8 children of a box share 2 candidate
+//    planes per axis (centre +- half/2), so one expansion is 6 slab-plane pairs
+//    + 8 max3/min3, with no child records loaded.  The child centres are
+//    recomputed with the builder's own expression (orig + (+-newlen2),
+//    raytrace.rs:816-824) and were verified bitwise at scene creation;
+//  * the stack of frames lives in LDS, [level][word][lane]: a lane only ever
+//    touches its own bank.
+//
+// Records (HBM, served from L2 / Infinity Cache):
+//   onodes  : float4 per box  (cx, cy, cz, link)
+//             link = low 24 bits | child_mask << 24.  Inner: low = index of the
+//             first child, mask = octants present (children stored in octant
+//             order).  Leaf: mask = 0, low = index of its first reference block.
+//   oblocks : uint4 blocks of triangle indices of a leaf, in list order,
+//             terminated by index 0 (the sentinel triangle is never in a tree,
+//             raytrace.rs:791), always at least one 0 at the end.
+#pragma once
+
+namespace rtmi {
+
+enum : uint32_t { M_IDLE = 0, M_SELECT = 1, M_LEAF = 2 };
+
+// frame words: w0 = first_child | mask << 24 ; w1 = order(24) | count << 24 | F_HAS | F_ANYMAX ; t ; tri|face<<30
+struct OFrame { uint32_t w0, w1; float t; uint32_t tri; };
+
+#define RTMI_REFILL_MIN 16
+
+template <bool COUNT>
+__device__ inline OFrame expand_oct(float cx, float cy, float cz, uint32_t link, float hc, const RayK& r,
+                                    unsigned long long* cnt) {
+    const uint32_t mask = link >> 24;
+    if (COUNT) { cnt[0] += __popc(mask); cnt[3]++; }
+    // candidate planes per axis (child centres: builder's orig.add(off_vec))
+    const float xl = cx + (-hc), xh = cx + hc, yl = cy + (-hc), yh = cy + hc, zl = cz + (-hc), zh = cz + hc;
+    const float bx = r.ix * hc, by = r.iy * hc, bz = r.iz * hc;  // tmp2 = inv_dir * len2
+    const float axl = (xl - r.ox) * r.ix, axh = (xh - r.ox) * r.ix;
+    const float ayl = (yl - r.oy) * r.iy, ayh = (yh - r.oy) * r.iy;
+    const float azl = (zl - r.oz) * r.iz, azh = (zh - r.oz) * r.iz;
+    // (near, far) per candidate: t1s = tmp1 - tmp2, t2s = tmp1 + tmp2, swapped when inv_dir <= 0
+    const bool px = r.ix > 0.f, py = r.iy > 0.f, pz = r.iz > 0.f;
+    float nx[2], fx[2], ny[2], fy[2], nz[2], fz[2];
+    { const float a = axl - bx, b = axl + bx; nx[0] = px ? a : b; fx[0] = px ? b : a; }
+    { const float a = axh - bx, b = axh + bx; nx[1] = px ? a : b; fx[1] = px ? b : a; }
+    { const float a = ayl - by, b = ayl + by; ny[0] = py ? a : b; fy[0] = py ? b : a; }
+    { const float a = ayh - by, b = ayh + by; ny[1] = py ? a : b; fy[1] = py ? b : a; }
+    { const float a = azl - bz, b = azl + bz; nz[0] = pz ? a : b; fz[0] = pz ? b : a; }
+    { const float a = azh - bz, b = azh + bz; nz[1] = pz ? a : b; fz[1] = pz ? b : a; }
+    // a zero direction component skips its slab (raytrace.rs:872, :882, :892): axis 0 then leaves the
+    // initial (-MAX, MAX); for axes 1, 2 a NaN operand makes fmaxf/fminf return the running value.
+    if (!(r.dx != 0.f)) { nx[0] = nx[1] = -FLT_MAX; fx[0] = fx[1] = FLT_MAX; }
+    if (!(r.dy != 0.f)) { ny[0] = ny[1] = fy[0] = fy[1] = __uint_as_float(0x7FC00000u); }
+    if (!(r.dz != 0.f)) { nz[0] = nz[1] = fz[0] = fz[1] = __uint_as_float(0x7FC00000u); }
+    float tm[8];
+    bool anymax = false;
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+        const float tmin = fmaxf(fmaxf(nx[o & 1], ny[(o >> 1) & 1]), nz[o >> 2]);
+        const float tmax = fminf(fminf(fx[o & 1], fy[(o >> 1) & 1]), fz[o >> 2]);
+        const bool hit = ((mask >> o) & 1u) && (tmin < tmax);
+        tm[o] = hit ? tmin : INFINITY;
+        anymax |= hit && (tmin == FLT_MAX);
+    }
+    // stable ascending order of the colliding children (insertion sort of raytrace.rs:941-947)
+    uint32_t order = 0, nh = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t rank = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j < i) rank += (tm[j] <= tm[i]) ? 1u : 0u;
+            if (j > i) rank += (tm[j] < tm[i]) ? 1u : 0u;
+        }
+        if (tm[i] != INFINITY) { order |= (uint32_t)i << (3u * rank); nh++; }
+    }
+    OFrame f;
+    f.w0 = link;
+    f.w1 = order | (nh << 24) | (anymax ? F_ANYMAX : 0u);
+    f.t = 0.f;
+    f.tri = 0;
+    return f;
+}
+
+__device__ inline void omerge(OFrame& f, bool have, float t, uint32_t tf) {
+    if (have) {
+        if (!(f.w1 & F_HAS) || t < f.t) { f.t = t; f.tri = tf; }
+        f.w1 |= F_HAS;
+    }
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(64) k_trace_oct(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
+                                                  DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
+                                                  float* __restrict__ hit_t) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x;  // one wave per block
+    constexpr int NT = 64;
+    const uint32_t count = ctrl->count[pass];
+    if (blockIdx.x == 0 && lane == 0) atomicAdd(&ctrl->rays, (unsigned long long)count);
+    unsigned long long cnt[5] = {0, 0, 0, 0, 0};
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const float root_half = sc.root_half;
+
+    uint32_t mode = M_IDLE;
+    bool exhausted = false;  // wave-uniform
+    RayK r = make_rayk(make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 1.f, 0.f));
+    uint32_t ridx = 0;
+    OFrame cur{0, 0, 0.f, 0};
+    int sp = 0;
+    uint4 blk = make_uint4(0, 0, 0, 0);  // current reference block of the leaf being scanned
+    uint32_t lblock = 0;
+    bool lhave = false;
+    float lt = 0.f;
+    uint32_t ltf = 0;
+
+    for (;;) {
+        const unsigned long long m_idle = __ballot(mode == M_IDLE);
+        if (m_idle == ~0ull && exhausted) break;
+        if (!exhausted && (__popcll(m_idle) >= RTMI_REFILL_MIN || m_idle == ~0ull)) {
+            // ---- refill: idle lanes take consecutive queued rays
+            const uint32_t n = (uint32_t)__popcll(m_idle);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&ctrl->head[pass], n);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base + n >= count) exhausted = true;
+            if (mode == M_IDLE) {
+                const uint32_t i = base + (uint32_t)__popcll(m_idle & lt_mask);
+                if (i < count) {
+                    ridx = i;
+                    r = make_rayk(qo[i], qd[i]);
+                    // virtual frame whose only child is the root box (index 0): the root itself is never
+                    // slab-tested (raytrace.rs:1272 calls get_object_intersection_for_ray on it directly)
+                    cur.w0 = 0u | (1u << 24);
+                    cur.w1 = 0u | (1u << 24);
+                    cur.t = 0.f; cur.tri = 0;
+                    sp = 0;
+                    mode = M_SELECT;
+                }
+            }
+            continue;
+        }
+        const int nS = __popcll(__ballot(mode == M_SELECT));
+        const int nL = __popcll(__ballot(mode == M_LEAF));
+        if (nS >= nL) {
+            // ================================================= SELECT step
+            if (mode == M_SELECT) {
+                // pop finished frames
+                while (F_COUNT(cur.w1) == 0) {
+                    if (sp == 0) {
+                        const bool have = (cur.w1 & F_HAS) != 0;
+                        hit_tf[ridx] = have ? cur.tri : 0u;
+                        hit_t[ridx] = have ? cur.t : 0.f;
+                        mode = M_IDLE;
+                        break;
+                    }
+                    const bool have = (cur.w1 & F_HAS) != 0;
+                    const float ct = cur.t;
+                    const uint32_t ctf = cur.tri;
+                    sp--;
+                    const uint32_t* fr = lds + sp * 4 * NT + lane;
+                    cur.w0 = fr[0];
+                    cur.w1 = fr[NT];
+                    cur.t = __uint_as_float(fr[2 * NT]);
+                    cur.tri = fr[3 * NT];
+                    omerge(cur, have, ct, ctf);
+                }
+                if (mode == M_SELECT) {
+                    const uint32_t o = cur.w1 & 7u;
+                    cur.w1 = ((cur.w1 & 0x00FFFFFFu) >> 3) | ((cur.w1 & 0xFF000000u) - (1u << 24));
+                    const uint32_t cidx = (cur.w0 & 0x00FFFFFFu) + (uint32_t)__popc((cur.w0 >> 24) & ((1u << o) - 1u));
+                    const float4 rec = sc.onodes[cidx];
+                    const float hc = ldexpf(root_half, -sp);  // half edge of a box at depth sp
+                    bool go = true;
+                    if (cur.w1 & (F_HAS | F_ANYMAX)) {
+                        float tmin;
+                        collides(rec.x, rec.y, rec.z, hc, r, tmin);
+                        if (cur.w1 & F_HAS) {
+                            if (!(tmin < cur.t)) { cur.w1 &= ~(15u << 24); go = false; }  // raytrace.rs:965; later children are farther
+                        } else if (tmin == FLT_MAX) go = false;                           // raytrace.rs:986
+                    }
+                    if (go) {
+                        const uint32_t link = __float_as_uint(rec.w);
+                        if ((link >> 24) == 0u) {
+                            lblock = link;
+                            blk = sc.oblocks[lblock];
+                            lhave = false; lt = 0.f; ltf = 0;
+                            if (COUNT) cnt[4]++;
+                            mode = M_LEAF;
+                        } else {
+                            uint32_t* fr = lds + sp * 4 * NT + lane;
+                            fr[0] = cur.w0;
+                            fr[NT] = cur.w1;
+                            fr[2 * NT] = __float_as_uint(cur.t);
+                            fr[3 * NT] = cur.tri;
+                            sp++;
+                            cur = expand_oct<COUNT>(rec.x, rec.y, rec.z, link, ldexpf(root_half, -sp), r, cnt);
+                        }
+                    }
+                }
+            }
+        } else {
+            // ================================================= LEAF step: one block of <= 4 references
+            if (mode == M_LEAF) {
+                const uint32_t ids[4] = {blk.x, blk.y, blk.z, blk.w};
+                float4 p0[4], p1[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { p0[k] = sc.tplane[2 * ids[k]]; p1[k] = sc.tplane[2 * ids[k] + 1]; }
+                const bool more = blk.w != 0u;
+                if (more) { lblock++; blk = sc.oblocks[lblock]; }  // prefetch the next block
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (ids[k] != 0u) {
+                        // Triangle::intersects (raytrace.rs:400-439), see tri_test() for the lane-3 terms
+                        const float ax = p0[k].x - r.ox, ay = p0[k].y - r.oy, az = p0[k].z - r.oz;
+                        const float num = (((0.f + p1[k].x * ax) + p1[k].y * ay) + p1[k].z * az) + r.qn;
+                        const float den = (((0.f + p1[k].x * r.dx) + p1[k].y * r.dy) + p1[k].z * r.dz) + r.qd;
+                        const float t = num / den;
+                        if (COUNT) cnt[1]++;
+                        if (!(t < 0.f)) {
+                            const float px = r.dx * t + r.ox, py = r.dy * t + r.oy, pz = r.dz * t + r.oz, pw = r.dw * t + r.ow;
+                            const float ix = px - p0[k].x, iy = py - p0[k].y, iz = pz - p0[k].z;
+                            const float l2 = ((ix * ix + iy * iy) + iz * iz) + pw * pw;
+                            if (!(l2 > p0[k].w)) {
+                                if (COUNT) cnt[2]++;
+                                const uint32_t tri = ids[k];
+                                const float4 e0 = sc.tedge[4 * tri], e1 = sc.tedge[4 * tri + 1], e2 = sc.tedge[4 * tri + 2], e3 = sc.tedge[4 * tri + 3];
+                                const float z = pw * 0.f;
+                                const float d0 = ((ix * e0.x + iy * e0.y) + iz * e0.z) + z;
+                                const float d1 = ((ix * e1.x + iy * e1.y) + iz * e1.z) + z;
+                                const float d2 = ((ix * e2.x + iy * e2.y) + iz * e2.z) + z;
+                                if (!(d0 > e0.w) && !(d1 > e1.w) && !(d2 > e2.w)) {
+                                    const bool edge = (d0 > e3.x) | (d1 > e3.y) | (d2 > e3.z);
+                                    const uint32_t face = (den > 0.f ? 1u : 0u) | (edge ? 2u : 0u);
+                                    if (!lhave || t < lt) { lt = t; ltf = tri | (face << 30); }  // raytrace.rs:1028-1038
+                                    lhave = true;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (!more) {
+                    omerge(cur, lhave, lt, ltf);
+                    mode = M_SELECT;
+                }
+            }
+        }
+    }
+    if (COUNT) {
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (cnt[k]) atomicAdd(&ctrl->counters[k], cnt[k]);
+    }
+}
+
+}  // namespace rtmi

@@ -103,6 +103,15 @@ def test_render_canonical_spp4_seeded(canonical_pair, seed):
     assert ctx.total_rays == cn["rays"]
 
 
+def test_generic_tree_kernel_same_results(canonical_pair):
+    # RTMI_OPT_GENERIC: the kernel for trees that are not exact octrees (loads every child box)
+    R = _R()
+    ref, cn, img, ctx = _render_both(canonical_pair, 40, 24, 5, 3, seed=11, options=R.OPT_GENERIC | R.OPT_COUNTERS)
+    assert_bits_equal(ref, img, "image")
+    for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
+        assert ctx.stats[k] == cn[k], k
+
+
 def test_render_counters_match_oracle(canonical_pair):
     ref, cn, img, ctx = _render_both(canonical_pair, 32, 32, 5, 2, options=_R().OPT_COUNTERS)
     assert_bits_equal(ref, img, "image")
