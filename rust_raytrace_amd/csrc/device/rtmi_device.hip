@@ -84,6 +84,7 @@ struct DCtrl {
     uint32_t head[RTMI_MAX_PASSES + 1];   // work-fetch cursor of pass k
     unsigned long long rays;              // sum of count[] (the "Rays" statistic)
     unsigned long long counters[5];       // box_tests tri_tests full_tests nodes leaves
+    unsigned long long dbg[16];           // step statistics of the counting build (tools/step_stats.py)
 };
 
 // ---------------------------------------------------------------- ray for the hot loops
@@ -860,7 +861,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
         return RTMI_OK;
     }
     // batch = whole pixels with all their samples
-    const size_t want_paths = env_size("RTMI_BATCH_PATHS", (size_t)16 << 20);
+    const size_t want_paths = env_size("RTMI_BATCH_PATHS", (size_t)128 << 20);
     uint64_t pix_per_batch = std::max<uint64_t>(1, want_paths / spp);
     pix_per_batch = std::min<uint64_t>(pix_per_batch, npix);
     if (pix_per_batch * spp >= (1ull << 31)) return fail(RTMI_ERR_UNSUPPORTED, "batch above 2^31 paths");
@@ -898,6 +899,22 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
             if (counting) launch_trace<true>(s, st, s->qo[a].p, s->qd[a].p, (int)pass);
             else launch_trace<false>(s, st, s->qo[a].p, s->qd[a].p, (int)pass);
             HIPCHK(hipEventRecord(s->pass_ev[2 * pass + 1], st));
+            if (counting && getenv("RTMI_VERBOSE")) {
+                DCtrl hc2;
+                HIPCHK(hipMemcpyAsync(&hc2, s->ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                static unsigned long long prev[5 + 8];
+                if (pass == 0) memset(prev, 0, sizeof(prev));
+                unsigned long long cur[13];
+                for (int k = 0; k < 5; k++) cur[k] = hc2.counters[k];
+                for (int k = 0; k < 8; k++) cur[5 + k] = hc2.dbg[k];
+                const double n = hc2.count[pass] ? (double)hc2.count[pass] : 1.0;
+                fprintf(stderr, "[rtmi]   pass %u per ray: box %.1f tri %.1f full %.2f nodes %.1f leaves %.1f | S-steps %.1f (util %.2f) L-steps %.1f (util %.2f)\n",
+                        pass, (cur[0] - prev[0]) / n, (cur[1] - prev[1]) / n, (cur[2] - prev[2]) / n, (cur[3] - prev[3]) / n, (cur[4] - prev[4]) / n,
+                        (cur[6] - prev[6]) / n, (double)(cur[6] - prev[6]) / (64.0 * (cur[5] - prev[5] ? cur[5] - prev[5] : 1)),
+                        (cur[8] - prev[8]) / n, (double)(cur[8] - prev[8]) / (64.0 * (cur[7] - prev[7] ? cur[7] - prev[7] : 1)));
+                memcpy(prev, cur, sizeof(prev));
+            }
             hipLaunchKernelGGL(k_shade, dim3(ew_blocks), dim3(256), 0, st, s->d, dv, seed, pix0, npaths, (int)pass,
                                s->qo[a].p, s->qd[a].p, s->qpath[a].p, s->hit_tf.p, s->hit_t.p, s->qo[b].p, s->qd[b].p,
                                s->qpath[b].p, s->mstack.p, s->scol.p, s->ctrl.p);
@@ -911,10 +928,14 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
         if (rc != RTMI_OK) return rc;
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+        DCtrl hc;
+        const bool verbose = getenv("RTMI_VERBOSE") != nullptr;
+        if (verbose) HIPCHK(hipMemcpy(&hc, s->ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost));
         for (uint32_t pass = 0; pass < maxdepth; pass++) {
             float pm = 0.f;
             HIPCHK(hipEventElapsedTime(&pm, s->pass_ev[2 * pass], s->pass_ev[2 * pass + 1]));
             tms += pm;
+            if (verbose) fprintf(stderr, "[rtmi] batch@%llu pass %u: %u rays, trace %.3f ms, %.1f Mrays/s\n", (unsigned long long)p0, pass, hc.count[pass], pm, hc.count[pass] / (pm * 1e3));
         }
         kernel_ms += ms; trace_ms += tms;
         if (stats) {
@@ -968,6 +989,16 @@ int rtmi_trace(rtmi_scene_t* s, uint64_t n, const float* orig4, const float* dir
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
     return read_stats(s, st, stats, ms, ms, 1);
+}
+
+// Development aid (not in rtmi.h): step statistics of the last counting render/trace.
+int rtmi_debug_counters(rtmi_scene_t* s, unsigned long long* out16) {
+    if (!s || !out16) return fail(RTMI_ERR_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(s->device));
+    DCtrl h;
+    HIPCHK(hipMemcpy(&h, s->ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost));
+    memcpy(out16, h.dbg, sizeof(h.dbg));
+    return RTMI_OK;
 }
 
 int rtmi_quantize(rtmi_scene_t* s, const float* rgba_host, uint64_t npixels, uint8_t* rgb_host) {

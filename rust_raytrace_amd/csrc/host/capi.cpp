@@ -191,6 +191,12 @@ int rth_caster_trace(rth_scene_t* s, uint64_t n, const float* o4, const float* d
     });
 }
 
+// development aid (tools/step_stats.py); not declared in rtmi_host.h
+int rtmi_debug_counters(rtmi_scene_t* s, unsigned long long* out16);
+int rth_debug_counters(rth_scene_t* s, unsigned long long* out16) {
+    return guarded([&] { rtmi_debug_counters(caster_of(s).resident(s->scene), out16); });
+}
+
 void rth_quantize(const float* rgba, uint64_t npixels, uint8_t* rgb) {
     quantize_rgb8(reinterpret_cast<const Color*>(rgba), (size_t)npixels, rgb);
 }
