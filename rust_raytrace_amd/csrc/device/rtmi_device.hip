@@ -800,7 +800,8 @@ extern "C++" {
 template <bool COUNT>
 static void launch_trace(rtmi_scene* s, hipStream_t st, const float4* qo, const float4* qd, int pass) {
     if (s->octree && !(s->options & RTMI_OPT_GENERIC)) {
-        dim3 grid((unsigned)(s->num_cu * s->oct_blocks_per_cu)), block(64);
+        const int per_cu = (int)env_size("RTMI_OCT_WAVES_PER_CU", (size_t)s->oct_blocks_per_cu);
+        dim3 grid((unsigned)(s->num_cu * per_cu)), block(64);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT>), grid, block, s->oct_lds, st, s->d, qo, qd, s->ctrl.p, pass,
                            s->hit_tf.p, s->hit_t.p);
         return;

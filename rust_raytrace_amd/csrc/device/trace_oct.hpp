@@ -68,25 +68,35 @@ __device__ inline OFrame expand_oct(float cx, float cy, float cz, uint32_t link,
     if (!(r.dz != 0.f)) { nz[0] = nz[1] = fz[0] = fz[1] = __uint_as_float(0x7FC00000u); }
     float tm[8];
     bool anymax = false;
+    uint32_t nh = 0;
 #pragma unroll
     for (int o = 0; o < 8; o++) {
         const float tmin = fmaxf(fmaxf(nx[o & 1], ny[(o >> 1) & 1]), nz[o >> 2]);
         const float tmax = fminf(fminf(fx[o & 1], fy[(o >> 1) & 1]), fz[o >> 2]);
         const bool hit = ((mask >> o) & 1u) && (tmin < tmax);
-        tm[o] = hit ? tmin : INFINITY;
+        tm[o] = hit ? tmin : INFINITY;  // a colliding tmin is never NaN (tmin < tmax held) and never +inf
         anymax |= hit && (tmin == FLT_MAX);
+        nh += hit ? 1u : 0u;
     }
-    // stable ascending order of the colliding children (insertion sort of raytrace.rs:941-947)
-    uint32_t order = 0, nh = 0;
+    // Stable ascending order of the colliding children (insertion sort of raytrace.rs:941-947) as a
+    // rank: child i goes after every j < i with tm[j] <= tm[i] and every k > i with tm[k] < tm[i].
+    // One compare per pair (no NaN among tm): c = tm[j] <= tm[k] puts j before k, !c puts k before j.
+    uint32_t A[8] = {0, 0, 0, 0, 0, 0, 0, 0}, B[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+#pragma unroll
+        for (int k = j + 1; k < 8; k++) {
+            const uint32_t c = (tm[j] <= tm[k]) ? 1u : 0u;
+            A[k] += c;
+            B[j] += c;
+        }
+    }
+    // non-colliding children (tm = +inf) rank last; their slots lie beyond `nh` and are never read
+    uint32_t order = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        uint32_t rank = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (j < i) rank += (tm[j] <= tm[i]) ? 1u : 0u;
-            if (j > i) rank += (tm[j] < tm[i]) ? 1u : 0u;
-        }
-        if (tm[i] != INFINITY) { order |= (uint32_t)i << (3u * rank); nh++; }
+        const uint32_t rank = A[i] + (uint32_t)(7 - i) - B[i];
+        order |= (uint32_t)i << (3u * rank);
     }
     OFrame f;
     f.w0 = link;
@@ -241,17 +251,20 @@ __global__ void __launch_bounds__(64) k_trace_oct(DScene sc, const float4* __res
                             if (!(l2 > p0[k].w)) {
                                 if (COUNT) { cnt[2]++; const unsigned long long em = __ballot(true); if (lane == __ffsll((long long)em) - 1) { dbg[6]++; dbg[7] += __popcll(em); } }
                                 const uint32_t tri = ids[k];
+                                // all four edge records are requested together and every comparison is
+                                // evaluated (no short-circuit): one memory round trip instead of three
                                 const float4 e0 = sc.tedge[4 * tri], e1 = sc.tedge[4 * tri + 1], e2 = sc.tedge[4 * tri + 2], e3 = sc.tedge[4 * tri + 3];
                                 const float z = pw * 0.f;
                                 const float d0 = ((ix * e0.x + iy * e0.y) + iz * e0.z) + z;
                                 const float d1 = ((ix * e1.x + iy * e1.y) + iz * e1.z) + z;
                                 const float d2 = ((ix * e2.x + iy * e2.y) + iz * e2.z) + z;
-                                if (!(d0 > e0.w) && !(d1 > e1.w) && !(d2 > e2.w)) {
-                                    const bool edge = (d0 > e3.x) | (d1 > e3.y) | (d2 > e3.z);
-                                    const uint32_t face = (den > 0.f ? 1u : 0u) | (edge ? 2u : 0u);
-                                    if (!lhave || t < lt) { lt = t; ltf = tri | (face << 30); }  // raytrace.rs:1028-1038
-                                    lhave = true;
-                                }
+                                const bool inside = !(d0 > e0.w) & !(d1 > e1.w) & !(d2 > e2.w);
+                                const bool edge = (d0 > e3.x) | (d1 > e3.y) | (d2 > e3.z);
+                                const uint32_t face = (den > 0.f ? 1u : 0u) | (edge ? 2u : 0u);
+                                const bool take = inside & (!lhave | (t < lt));  // raytrace.rs:1028-1038
+                                lt = take ? t : lt;
+                                ltf = take ? (tri | (face << 30)) : ltf;
+                                lhave = lhave | inside;
                             }
                         }
                     }
