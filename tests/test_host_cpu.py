@@ -1,0 +1,161 @@
+"""CPU: the product's host-side mirror (C++) against the oracle, and the C-ABI library surface."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import (GOLDEN, ROOT, TEAPOT, TEAPOT_TRI, assert_bits_equal, build_pair, recipe_axis_box, recipe_canonical,
+                      recipe_circles)
+
+
+def _R():
+    from rust_raytrace_amd import raytrace as R
+    return R
+
+
+def _compare_scenes(so, sp):
+    ro, ko, fo = so.triangles()
+    rp, kp, fp = sp.triangles()
+    assert_bits_equal(ro, rp, "triangle records")
+    assert np.array_equal(ko, kp)
+    assert_bits_equal(fo, fp, "surfaces")
+    go, to, refo = so.tree_flatten()
+    gp, tp, refp = sp.tree()
+    assert_bits_equal(go, gp, "box geometry")
+    assert np.array_equal(to, tp), "box topology"
+    assert np.array_equal(refo, refp), "leaf triangle lists"
+
+
+def test_canonical_scene_identical_to_oracle(canonical_pair):
+    _compare_scenes(*canonical_pair)
+
+
+def test_circles_scene_identical_to_oracle(circles_pair):
+    _compare_scenes(*circles_pair)
+
+
+@pytest.mark.parametrize("recipe", [recipe_axis_box(), recipe_canonical(accel="trivial", obj=TEAPOT),
+                                    recipe_canonical(maxdepth=4, minobjs=40), recipe_circles(maxdepth=3, minobjs=2)])
+def test_other_scenes_identical_to_oracle(recipe):
+    _compare_scenes(*build_pair(recipe))
+
+
+def test_octree_build_is_thread_count_independent():
+    R = _R()
+    a = R.canonical_scene(TEAPOT_TRI, maxdepth=5, minobjs=19, threads=1)
+    b = R.canonical_scene(TEAPOT_TRI, maxdepth=5, minobjs=19, threads=7)
+    ga, ta, ra = a.tree()
+    gb, tb, rb = b.tree()
+    assert_bits_equal(ga, gb, "geometry")
+    assert np.array_equal(ta, tb) and np.array_equal(ra, rb)
+
+
+def test_teapot_obj_files_are_the_same_geometry():
+    # the two OBJ files differ only in -0.0 vs +0.0 sign bits and vn / face syntax
+    R = _R()
+    a = R.Scene(False)
+    b = R.Scene(False)
+    t = R.create_transform(R.unit([0.0, 0.3, 1.0]), R.to_radians(270.0))
+    surf = R.SurfaceKind.Solid(R.make_color(1, 2, 3))
+    a.extend_parse_obj(TEAPOT_TRI, [0.0, 0.5, 5.0], 1.0, t, surf, 0.05)
+    b.extend_parse_obj(TEAPOT, [0.0, 0.5, 5.0], 1.0, t, surf, 0.05)
+    assert a.num_tris() == b.num_tris() == 6320
+    assert np.array_equal(a.triangles()[0], b.triangles()[0])  # numerically equal (== treats -0 as +0)
+
+
+def test_face_collision_known_answer_in_product_host():
+    # raytrace.rs:735-750 restated against the product's own builder code
+    R = _R()
+    s = R.Scene(False)
+    s.push_triangle(np.array([[1.0, 0.4, 0.2], [1.0, 0.2, -0.3], [0.6, 0.6, -0.5]], np.float32), R.SurfaceKind.Solid(R.make_color(0, 0, 0)), 0.0)
+    assert s.face_contains_triangle([2.0, 2.0, 2.0], [0.0, 0.0, -1.0], 2.0, 0)
+
+
+def test_viewport_and_transform_identical_to_oracle():
+    from oracle import orc
+    R = _R()
+    for d, roll in (([0.0, 0.3, 1.0], 270.0), ([1.0, 0.0, 0.0], 0.0), ([-0.2, 0.9, -0.4], 33.0)):
+        assert_bits_equal(orc.create_transform(orc.unit(d), orc.to_radians(roll)), R.create_transform(R.unit(d), R.to_radians(roll)), "transform")
+    for (w, h) in ((64, 64), (640, 480), (2048, 2048), (3, 7)):
+        assert_bits_equal(orc.canonical_viewport(w, h), R.canonical_viewport(w, h).vp12, "viewport")
+    assert_bits_equal(orc.make_color(128, 180, 255), R.make_color(128, 180, 255), "color")
+
+
+def test_reference_panics_become_errors(tmp_path):
+    R = _R()
+    s = R.Scene()
+    surf = R.SurfaceKind.Solid(R.make_color(1, 1, 1))
+    with pytest.raises(RuntimeError, match="degenerate"):
+        s.push_triangle(np.zeros((3, 3), np.float32), surf, 0.0)                       # unwrap() at raytrace.rs:357
+    with pytest.raises(RuntimeError, match="even"):
+        s.extend_make_sphere([0, 0, 5], 1.0, (3, 8), surf, 0.0)                         # assert!(num_lat % 2 == 0)
+    with pytest.raises(RuntimeError, match="cannot read"):
+        s.extend_parse_obj(str(tmp_path / "missing.obj"), [0, 0, 0], 1.0, np.eye(3).ravel(), surf, 0.0)
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n")
+    with pytest.raises(RuntimeError, match="out of range"):
+        s.extend_parse_obj(str(bad), [0, 0, 0], 1.0, np.eye(3).ravel(), surf, 0.0)      # index panic in obj_parser.rs:63
+    bad.write_text("v 0 0\n")
+    with pytest.raises(RuntimeError, match="3 numbers"):
+        s.extend_parse_obj(str(bad), [0, 0, 0], 1.0, np.eye(3).ravel(), surf, 0.0)      # assert!(parts.len() == 3)
+    far = R.Scene()
+    far.push_triangle(np.array([[0, 0, 1], [1, 0, 1], [0, 1, 1]], np.float32), surf, 0.0)
+    with pytest.raises(RuntimeError, match="root box"):
+        far.build_bounding_box([100.0, 100.0, 100.0], 1.0, 4, 2)                        # unwrap() at raytrace.rs:792
+
+
+def test_obj_parser_accepts_the_reference_syntax(tmp_path):
+    R = _R()
+    p = tmp_path / "q.obj"
+    p.write_text("# comment\nmtllib x.mtl\no thing\nv 0 0 5\r\nv 1 0 5\nv 0 1 5\nv 1 1 5\nvn 0 0 1\nvt 0 0\ns 0\n"
+                 "f 1//1 2//1 3//1\nf 2/7/1 4/8/1 3/9/1 1/1/1\n")
+    s = R.Scene(False)
+    s.extend_parse_obj(str(p), [0, 0, 0], 2.0, np.eye(3, dtype=np.float32).ravel(), R.SurfaceKind.Solid(R.make_color(9, 9, 9)), 0.0)
+    rec, _, _ = s.triangles()
+    assert rec.shape[0] == 2  # quads contribute their first three corners only (obj_parser.rs:63-65)
+    assert np.allclose(rec[0, 20:29].reshape(3, 3), [[0, 0, 10], [2, 0, 10], [0, 2, 10]])
+    assert np.allclose(rec[1, 20:29].reshape(3, 3), [[2, 0, 10], [2, 2, 10], [0, 2, 10]])
+
+
+def test_library_exports_every_declared_symbol():
+    from rust_raytrace_amd import _ffi
+    lib = _ffi.lib()
+    declared = set()
+    for hdr in ("rtmi.h", "rtmi_host.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        declared |= set(re.findall(r"\b(rtmi_[a-z_0-9]+|rth_[a-z_0-9]+)\s*\(", text))
+    declared = {d for d in declared if not d.endswith("_t")}  # type names mentioned in comments
+    assert declared == set(_ffi.RTMI_SYMBOLS) | set(_ffi.RTH_SYMBOLS), declared ^ (set(_ffi.RTMI_SYMBOLS) | set(_ffi.RTH_SYMBOLS))
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+
+
+def test_abi_struct_layouts():
+    from rust_raytrace_amd import _ffi
+    assert C.sizeof(_ffi.Stats) == 72 and C.sizeof(_ffi.Tile) == 16
+
+
+def test_no_cpu_fallback_without_a_gpu(canonical_pair):
+    """On a machine without a HIP device every render entry point must fail loudly."""
+    from rust_raytrace_amd import _ffi
+    if _ffi.lib().rtmi_device_count() > 0:
+        pytest.skip("a GPU is visible here; the failure path is for GPU-less hosts")
+    R = _R()
+    _, sp = canonical_pair
+    vp = R.canonical_viewport(8, 8, 5, 1)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        R.HipRayCaster().walk_rays(vp, sp, np.zeros((8, 8, 4), np.float32), 1, False)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        R.HipRayCaster().trace(sp, np.zeros((1, 4), np.float32), np.array([[0, 0, 1, 0]], np.float32))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rust_raytrace_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.replace("# oracle", "").lower() or f in (), f"{f} mentions the oracle"
+    for hdr in os.listdir(os.path.join(ROOT, "include")):
+        assert "oracle" not in open(os.path.join(ROOT, "include", hdr)).read().lower()
