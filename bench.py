@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--stripe-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
-    ap.add_argument("--cpu-sample", default="256x256x8", help="WxHxSPP of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", default="512x512x16", help="WxHxSPP of the CPU baseline sample")
     args = ap.parse_args()
 
     import numpy as np
