@@ -82,6 +82,8 @@ __device__ inline void tile_pixel(const DView& v, uint32_t lp, uint32_t& row, ui
 struct DCtrl {
     uint32_t count[RTMI_MAX_PASSES + 1];  // rays queued for pass k
     uint32_t head[RTMI_MAX_PASSES + 1];   // work-fetch cursor of pass k
+    uint32_t redo[RTMI_MAX_PASSES + 1];   // rays of pass k the octree kernel hands to the generic kernel (NaN hit times)
+    uint32_t redo_head[RTMI_MAX_PASSES + 1];
     unsigned long long rays;              // sum of count[] (the "Rays" statistic)
     unsigned long long counters[5];       // box_tests tri_tests full_tests nodes leaves
     unsigned long long dbg[16];           // step statistics of the counting build (tools/step_stats.py)
@@ -301,19 +303,23 @@ __device__ inline bool traverse(const DScene& sc, const RayK& r, uint32_t* lds, 
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_trace(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
                                                DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
-                                               float* __restrict__ hit_t) {
+                                               float* __restrict__ hit_t, const uint32_t* __restrict__ list) {
+    // list == nullptr: every ray of the pass.  list != nullptr: only the rays the octree kernel handed over
+    // (ctrl->redo[pass] of them); their work is not counted twice.
     extern __shared__ uint32_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t count = ctrl->count[pass];
-    if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctrl->rays, (unsigned long long)count);
+    const uint32_t count = list ? ctrl->redo[pass] : ctrl->count[pass];
+    uint32_t* head = list ? &ctrl->redo_head[pass] : &ctrl->head[pass];
+    if (!list && blockIdx.x == 0 && tid == 0) atomicAdd(&ctrl->rays, (unsigned long long)count);
     unsigned long long cnt[5] = {0, 0, 0, 0, 0};
     for (;;) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctrl->head[pass], 64u);
+        if (lane == 0) base = atomicAdd(head, 64u);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= count) break;
-        const uint32_t i = base + lane;
-        if (i < count) {
+        const uint32_t j = base + lane;
+        if (j < count) {
+            const uint32_t i = list ? list[j] : j;
             const RayK r = make_rayk(qo[i], qd[i]);
             float t = 0.f; uint32_t tf = 0;
             bool have = traverse<COUNT>(sc, r, lds, blockDim.x, tid, t, tf, cnt);
@@ -321,7 +327,7 @@ __global__ void __launch_bounds__(256) k_trace(DScene sc, const float4* __restri
             hit_t[i] = have ? t : 0.f;
         }
     }
-    if (COUNT) {
+    if (COUNT && !list) {
 #pragma unroll
         for (int k = 0; k < 5; k++)
             if (cnt[k]) atomicAdd(&ctrl->counters[k], cnt[k]);
@@ -552,7 +558,7 @@ struct rtmi_scene {
     size_t cap = 0;
     uint32_t cap_depth = 0;
     DevBuf<float4> qo[2], qd[2], scol, tile;
-    DevBuf<uint32_t> qpath[2], hit_tf;
+    DevBuf<uint32_t> qpath[2], hit_tf, redo;
     DevBuf<float> hit_t;
     DevBuf<uint16_t> mstack;
     DevBuf<DCtrl> ctrl;
@@ -746,7 +752,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
                   (uint32_t)nboxes, (uint32_t)ntris, (uint32_t)matmap.size(), levels,
                   s->octree ? s->onodes.p : nullptr, s->octree ? s->oblocks.p : nullptr, boxes[0].len2, max_inner_depth + 1};
     if (s->octree) {
-        s->oct_lds = (size_t)(max_inner_depth + 1) * 16 * 64;
+        s->oct_lds = (size_t)std::max<uint32_t>(1u, max_inner_depth) * 12 * 64;  // 3 words per level per lane
         if (s->oct_lds > 64 * 1024) { s->octree = false; s->why_generic = "octree deeper than the LDS stack allows"; }
         else {
             int nb = 0;
@@ -764,7 +770,7 @@ int rtmi_scene_destroy(rtmi_scene_t* s) {
     s->nodes.release(); s->refs.release(); s->tplane.release(); s->tedge.release(); s->mats.release();
     s->onodes.release(); s->oblocks.release();
     for (int k = 0; k < 2; k++) { s->qo[k].release(); s->qd[k].release(); s->qpath[k].release(); }
-    s->scol.release(); s->tile.release(); s->hit_tf.release(); s->hit_t.release(); s->mstack.release();
+    s->scol.release(); s->tile.release(); s->hit_tf.release(); s->redo.release(); s->hit_t.release(); s->mstack.release();
     s->ctrl.release(); s->qbytes.release();
     for (int k = 0; k < 4; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
     for (hipEvent_t e : s->pass_ev) (void)hipEventDestroy(e);
@@ -789,6 +795,7 @@ static int ensure_workspace(rtmi_scene* s, size_t cap, uint32_t maxdepth) {
     }
     HIPCHK(s->scol.ensure(cap));
     HIPCHK(s->hit_tf.ensure(cap));
+    HIPCHK(s->redo.ensure(cap));
     HIPCHK(s->hit_t.ensure(cap));
     HIPCHK(s->mstack.ensure(cap * (size_t)maxdepth));
     s->cap = cap;
@@ -803,14 +810,17 @@ static void launch_trace(rtmi_scene* s, hipStream_t st, const float4* qo, const 
         const int per_cu = (int)env_size("RTMI_OCT_WAVES_PER_CU", (size_t)s->oct_blocks_per_cu);
         dim3 grid((unsigned)(s->num_cu * per_cu)), block(64);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT>), grid, block, s->oct_lds, st, s->d, qo, qd, s->ctrl.p, pass,
-                           s->hit_tf.p, s->hit_t.p);
+                           s->hit_tf.p, s->hit_t.p, s->redo.p);
+        // exact re-trace of the (normally zero) rays whose leaf results contained a NaN hit time
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<false>), dim3(16), dim3((unsigned)s->trace_block), s->trace_lds, st, s->d, qo, qd,
+                           s->ctrl.p, pass, s->hit_tf.p, s->hit_t.p, (const uint32_t*)s->redo.p);
         return;
     }
     // persistent grid: enough blocks to fill every CU at the occupancy LDS allows
     const int per_cu = s->trace_block == 256 ? 4 : 16;
     dim3 grid((unsigned)(s->num_cu * per_cu)), block((unsigned)s->trace_block);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<COUNT>), grid, block, s->trace_lds, st, s->d, qo, qd, s->ctrl.p, pass,
-                       s->hit_tf.p, s->hit_t.p);
+                       s->hit_tf.p, s->hit_t.p, (const uint32_t*)nullptr);
 }
 }  // extern "C++"
 

@@ -36,8 +36,13 @@ namespace rtmi {
 
 enum : uint32_t { M_IDLE = 0, M_SELECT = 1, M_LEAF = 2 };
 
-// frame words: w0 = first_child | mask << 24 ; w1 = order(24) | count << 24 | F_HAS | F_ANYMAX ; t ; tri|face<<30
-struct OFrame { uint32_t w0, w1; float t; uint32_t tri; };
+// frame words: w0 = first_child | mask << 24 ; w1 = order(24) | count << 24 | F_HAS | F_ANYMAX ; t = best hit
+// time inside this frame's subtree (what the sibling-local skip rule compares against).
+// Which triangle that was is NOT kept per frame: the ray keeps one running best (t, tri) over its leaf results in
+// visiting order.  Merging with strict `<` is associative as long as no leaf result has a NaN time, so the running
+// best equals the reference's nested per-box results; a ray that meets a NaN leaf result (a 0/0 plane test that comes
+// first in a leaf) is re-traced by the generic kernel, which merges box by box.  3 words per level instead of 4.
+struct OFrame { uint32_t w0, w1; float t; };
 
 #define RTMI_REFILL_MIN 16
 
@@ -102,21 +107,20 @@ __device__ inline OFrame expand_oct(float cx, float cy, float cz, uint32_t link,
     f.w0 = link;
     f.w1 = order | (nh << 24) | (anymax ? F_ANYMAX : 0u);
     f.t = 0.f;
-    f.tri = 0;
     return f;
 }
 
-__device__ inline void omerge(OFrame& f, bool have, float t, uint32_t tf) {
+__device__ inline void omerge(OFrame& f, bool have, float t) {
     if (have) {
-        if (!(f.w1 & F_HAS) || t < f.t) { f.t = t; f.tri = tf; }
+        if (!(f.w1 & F_HAS) || t < f.t) f.t = t;
         f.w1 |= F_HAS;
     }
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(64) k_trace_oct(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
+__global__ void __launch_bounds__(64, 6) k_trace_oct(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
                                                   DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
-                                                  float* __restrict__ hit_t) {
+                                                  float* __restrict__ hit_t, uint32_t* __restrict__ redo) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;  // one wave per block
     constexpr int NT = 64;
@@ -131,8 +135,11 @@ __global__ void __launch_bounds__(64) k_trace_oct(DScene sc, const float4* __res
     bool exhausted = false;  // wave-uniform
     RayK r = make_rayk(make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 1.f, 0.f));
     uint32_t ridx = 0;
-    OFrame cur{0, 0, 0.f, 0};
-    int sp = 0;
+    OFrame cur{0, 0, 0.f};
+    int lvl = -1;  // depth of the current frame's box; -1 = the virtual frame above the root
+    bool ghave = false, gnan = false;  // running best over the ray's leaf results
+    float gt = 0.f;
+    uint32_t gtf = 0;
     uint4 blk = make_uint4(0, 0, 0, 0);  // current reference block of the leaf being scanned
     uint32_t lblock = 0;
     bool lhave = false;
@@ -159,8 +166,9 @@ __global__ void __launch_bounds__(64) k_trace_oct(DScene sc, const float4* __res
                     // slab-tested (raytrace.rs:1272 calls get_object_intersection_for_ray on it directly)
                     cur.w0 = 0u | (1u << 24);
                     cur.w1 = 0u | (1u << 24);
-                    cur.t = 0.f; cur.tri = 0;
-                    sp = 0;
+                    cur.t = 0.f;
+                    lvl = -1;
+                    ghave = false; gnan = false; gt = 0.f; gtf = 0;
                     mode = M_SELECT;
                 }
             }
@@ -172,32 +180,30 @@ __global__ void __launch_bounds__(64) k_trace_oct(DScene sc, const float4* __res
         if (nS >= nL) {  // majority vote; hysteresis (stay in a phase until its lanes fall below 1/2..1/8 of the other's) measured 1-7 % slower
             // ================================================= SELECT step
             if (mode == M_SELECT) {
-                // pop finished frames
+                // pop finished frames; the frames of depth 0 .. lvl-1 are in LDS levels 0 .. lvl-1
                 while (F_COUNT(cur.w1) == 0) {
-                    if (sp == 0) {
-                        const bool have = (cur.w1 & F_HAS) != 0;
-                        hit_tf[ridx] = have ? cur.tri : 0u;
-                        hit_t[ridx] = have ? cur.t : 0.f;
+                    if (lvl <= 0) {
+                        hit_tf[ridx] = ghave ? gtf : 0u;
+                        hit_t[ridx] = ghave ? gt : 0.f;
+                        if (gnan) redo[atomicAdd(&ctrl->redo[pass], 1u)] = ridx;  // rare: exact box-by-box merge needed
                         mode = M_IDLE;
                         break;
                     }
                     const bool have = (cur.w1 & F_HAS) != 0;
                     const float ct = cur.t;
-                    const uint32_t ctf = cur.tri;
-                    sp--;
-                    const uint32_t* fr = lds + sp * 4 * NT + lane;
+                    lvl--;
+                    const uint32_t* fr = lds + lvl * 3 * NT + lane;
                     cur.w0 = fr[0];
                     cur.w1 = fr[NT];
                     cur.t = __uint_as_float(fr[2 * NT]);
-                    cur.tri = fr[3 * NT];
-                    omerge(cur, have, ct, ctf);
+                    omerge(cur, have, ct);
                 }
                 if (mode == M_SELECT) {
                     const uint32_t o = cur.w1 & 7u;
                     cur.w1 = ((cur.w1 & 0x00FFFFFFu) >> 3) | ((cur.w1 & 0xFF000000u) - (1u << 24));
                     const uint32_t cidx = (cur.w0 & 0x00FFFFFFu) + (uint32_t)__popc((cur.w0 >> 24) & ((1u << o) - 1u));
                     const float4 rec = sc.onodes[cidx];
-                    const float hc = ldexpf(root_half, -sp);  // half edge of a box at depth sp
+                    const float hc = ldexpf(root_half, -(lvl + 1));  // half edge of the child (depth lvl + 1)
                     bool go = true;
                     if (cur.w1 & (F_HAS | F_ANYMAX)) {
                         float tmin;
@@ -215,13 +221,14 @@ __global__ void __launch_bounds__(64) k_trace_oct(DScene sc, const float4* __res
                             if (COUNT) cnt[4]++;
                             mode = M_LEAF;
                         } else {
-                            uint32_t* fr = lds + sp * 4 * NT + lane;
-                            fr[0] = cur.w0;
-                            fr[NT] = cur.w1;
-                            fr[2 * NT] = __float_as_uint(cur.t);
-                            fr[3 * NT] = cur.tri;
-                            sp++;
-                            cur = expand_oct<COUNT>(rec.x, rec.y, rec.z, link, ldexpf(root_half, -sp), r, cnt);
+                            if (lvl >= 0) {  // the virtual frame needs no slot: it has nothing left to do
+                                uint32_t* fr = lds + lvl * 3 * NT + lane;
+                                fr[0] = cur.w0;
+                                fr[NT] = cur.w1;
+                                fr[2 * NT] = __float_as_uint(cur.t);
+                            }
+                            lvl++;
+                            cur = expand_oct<COUNT>(rec.x, rec.y, rec.z, link, ldexpf(root_half, -(lvl + 1)), r, cnt);
                         }
                     }
                 }
@@ -270,7 +277,12 @@ __global__ void __launch_bounds__(64) k_trace_oct(DScene sc, const float4* __res
                     }
                 }
                 if (!more) {
-                    omerge(cur, lhave, lt, ltf);
+                    omerge(cur, lhave, lt);
+                    if (lhave) {
+                        if (!ghave || lt < gt) { gt = lt; gtf = ltf; }
+                        ghave = true;
+                        gnan |= (lt != lt);
+                    }
                     mode = M_SELECT;
                 }
             }
