@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--maxdepth", type=int, default=5)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--stripe-rows", type=int, default=16)
+    ap.add_argument("--backend", default="nccl", help="nccl (RCCL, one rank per GPU) or gloo (rehearsal: ranks may share a GPU)")
+    ap.add_argument("--check", action="store_true", help="rank 0 verifies the gathered frame against a single-tile render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
     ap.add_argument("--cpu-sample", default="512x512x16", help="WxHxSPP of the CPU baseline sample")
@@ -51,11 +53,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    ndev = torch.cuda.device_count()
+    if args.backend == "gloo":
+        local_rank = local_rank % max(ndev, 1)  # rehearsal: several ranks on one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     obj = os.path.join(ROOT, "tests", "golden", "teapot_tri.obj")
     t0 = time.time()
@@ -154,6 +162,14 @@ def main():
                             "sample": f"canonical scene, same camera, {cw}x{ch} @ {cspp} spp, depth {args.maxdepth}: "
                                       f"{cn['rays']} rays in {cdt:.2f} s wall"}
 
+        if args.check:
+            ref = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+            caster.walk_tile_device(vp, scene, (0, H, H, 0), ref.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            same = bool(torch.equal(ref.view(torch.int32), frame.view(torch.int32)))
+            print(f"[bench] gathered frame == single-tile render: {same}", file=sys.stderr)
+            if not same:
+                raise SystemExit("gathered frame differs from the single-tile render")
         value = rays / dt / 1e6
         out = {
             "metric": "Mrays/s, teapot_tri.obj 2048x2048 @64spp (primary + bounce rays per second of frame time)",

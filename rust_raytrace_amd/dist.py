@@ -63,6 +63,8 @@ def gather_frame(local, rank, world, height, width, stripe_rows=DEFAULT_STRIPE_R
         send = torch.zeros((mr, width, 4), dtype=local.dtype, device=local.device)
         send[: local.shape[0]] = local
     send = send.contiguous()
+    if dist.get_backend(group) == "gloo" and send.is_cuda:
+        send = send.cpu()  # gloo moves host memory (CPU tests, and rehearsing N ranks on one GPU)
     bands = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
     dist.gather(send, bands, dst=dst, group=group)
     if rank != dst:
@@ -70,5 +72,5 @@ def gather_frame(local, rank, world, height, width, stripe_rows=DEFAULT_STRIPE_R
     frame = torch.empty((height, width, 4), dtype=local.dtype, device=local.device)
     for r in range(world):
         rows = tile_rows_for(r, world, height, stripe_rows)
-        frame[torch.as_tensor(rows, device=local.device)] = bands[r][: len(rows)]
+        frame[torch.as_tensor(rows, device=local.device)] = bands[r][: len(rows)].to(local.device)
     return frame
