@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--maxdepth", type=int, default=5)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--stripe-rows", type=int, default=16)
+    ap.add_argument("--scene", default="canonical", choices=["canonical", "grid", "linear"],
+                    help="canonical = config 3 (default, the headline); grid = config 5 (8 teapots); linear = config 2 (trivial box)")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, one rank per GPU) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--check", action="store_true", help="rank 0 verifies the gathered frame against a single-tile render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -67,7 +69,12 @@ def main():
 
     obj = os.path.join(ROOT, "tests", "golden", "teapot_tri.obj")
     t0 = time.time()
-    scene = R.canonical_scene(obj)  # octree (10, 19)
+    if args.scene == "grid":
+        scene = R.grid_scene(obj)
+    elif args.scene == "linear":
+        scene = R.canonical_scene(os.path.join(ROOT, "tests", "golden", "teapot.obj"), accel="trivial")
+    else:
+        scene = R.canonical_scene(obj)  # octree (10, 19)
     t_build = time.time() - t0
     W, H, spp = args.width, args.height, args.spp
     vp = R.canonical_viewport(W, H, args.maxdepth, spp)
@@ -149,7 +156,7 @@ def main():
                         "bytes_per_ray": round(alg_bytes / max(st["rays"], 1), 1),
                         "trace_share_of_kernel_time": round(trace_ms / max(kernel_ms, 1e-9), 3),
                         "note": "served from L2/Infinity Cache (scene ~19 MB); VALU/latency-bound, see DESIGN.md"}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.scene == "canonical":
             from oracle import orc
             cw, ch, cspp = (int(x) for x in args.cpu_sample.split("x"))
             so = orc.canonical_scene(obj)
@@ -176,7 +183,9 @@ def main():
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "s_per_frame": round(dt / args.steps, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"canonical main.rs scene (teapot_tri.obj + 2 mirror disks, 6721 triangles), octree (10,19), "
+            "config": {"workload": {"canonical": "canonical main.rs scene (teapot_tri.obj + 2 mirror disks, 6721 triangles), octree (10,19), ",
+                                    "grid": "config 5: 8 x teapot_tri.obj grid (50561 triangles), octree (10,19), ",
+                                    "linear": "config 2: canonical scene from teapot.obj, trivial bounding box (linear list of 6720 triangles), "}[args.scene] +
                                    f"{W}x{H} @ {spp} spp, depth {args.maxdepth}, seed {args.seed}",
                        "tiling": f"{world} x interleaved {args.stripe_rows}-row stripes + one gather", "rays_per_frame": int(rays / args.steps)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,

@@ -270,6 +270,27 @@ def canonical_scene(obj_path, accel="octree", maxdepth=10, minobjs=19, teapot_su
     return s
 
 
+def grid_scene(obj_path, maxdepth=10, minobjs=19, n=8, threads=0):
+    """BASELINE config 5: n instances of teapot_tri.obj on a 2x2x2 grid (spacing 9 units) inside the canonical
+    root box — the octree-traversal stress scene (8 x 6320 + 1 = 50 561 triangles)."""
+    s = Scene(with_dummy=True)
+    surfs = [SurfaceKind.Matte(make_color(252, 119, 0), 0.2), SurfaceKind.Reflective(0.01, make_color(200, 200, 220), 0.6),
+             SurfaceKind.Solid(make_color(30, 160, 60)), SurfaceKind.Matte(make_color(200, 40, 40), 0.35)]
+    k = 0
+    for iz in range(2):
+        for iy in range(2):
+            for ix in range(2):
+                if k >= n:
+                    break
+                off = [-4.5 + 9.0 * ix, -4.5 + 9.0 * iy, 9.0 + 9.0 * iz]
+                s.extend_parse_obj(obj_path, off, 1.0, create_transform(unit([0.0, 0.3, 1.0]), to_radians(270.0 + 20.0 * k)),
+                                   surfs[k % 4], 0.05 if k % 2 == 0 else 0.0)
+                k += 1
+    s.populate_triangle_numbers()
+    s.build_bounding_box([0.0, 0.0, 20.1], 20.0, maxdepth, minobjs, threads)
+    return s
+
+
 def canonical_viewport(w, h, maxdepth=5, samples=1):
     """main.rs:166-173"""
     aspect = np.float32(h) / np.float32(w)

@@ -135,6 +135,28 @@ def recipe_canonical(accel="octree", maxdepth=10, minobjs=19, solid_teapot=False
     return r
 
 
+def recipe_grid(maxdepth=10, minobjs=19, n=8, obj=TEAPOT_TRI):
+    """BASELINE config 5: `n` instances of teapot_tri.obj on a 2x2x2 grid, spacing 9 units (instances do not
+    overlap; the teapot spans about +-3.4), inside the canonical root box (centre (0,0,20.1), half 20)."""
+    def r(api):
+        s = api.scene()
+        surfs = [api.matte((252, 119, 0), 0.2), api.reflective(0.01, (200, 200, 220), 0.6), api.solid((30, 160, 60)),
+                 api.matte((200, 40, 40), 0.35)]
+        k = 0
+        for iz in range(2):
+            for iy in range(2):
+                for ix in range(2):
+                    if k >= n:
+                        break
+                    off = [-4.5 + 9.0 * ix, -4.5 + 9.0 * iy, 9.0 + 9.0 * iz]
+                    api.add_obj(s, obj, off, 1.0, api.transform([0.0, 0.3, 1.0], 270.0 + 20.0 * k), surfs[k % 4], 0.05 if k % 2 == 0 else 0.0)
+                    k += 1
+        s.populate_triangle_numbers()
+        s.build_bounding_box([0.0, 0.0, 20.1], 20.0, maxdepth, minobjs)
+        return s
+    return r
+
+
 def recipe_circles(accel="octree", maxdepth=6, minobjs=8):
     """BASELINE config 1 ("circles"): the reference has no analytic sphere at this
     revision, so the scene is a ground disk plus tessellated make_sphere balls

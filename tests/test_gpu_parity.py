@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import (TEAPOT, assert_bits_equal, build_pair, recipe_axis_box, recipe_canonical, recipe_circles)
+from conftest import (TEAPOT, assert_bits_equal, build_pair, recipe_axis_box, recipe_canonical, recipe_circles, recipe_grid)
 
 pytestmark = pytest.mark.gpu
 
@@ -288,3 +288,13 @@ def test_full_size_properties_config3():
     sky = torch.tensor(_orc().make_color(128, 180, 255), device="cuda:0")
     assert torch.equal(whole[0, 0, :3], sky)
     assert not torch.equal(whole[H // 2 + 100, W // 2, :3], sky)
+
+
+def test_render_grid_config5_reduced():
+    # BASELINE config 5 scene (8 teapot instances, 50 561 triangles) with a shallower octree so that the
+    # single-threaded oracle builds it in seconds; mixed Matte / Reflective / Solid instances
+    pair = build_pair(recipe_grid(maxdepth=7, minobjs=19))
+    ref, cn, img, ctx = _render_both(pair, 48, 48, 5, 2, seed=21, options=_R().OPT_COUNTERS)
+    assert_bits_equal(ref, img, "image")
+    for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
+        assert ctx.stats[k] == cn[k], k
