@@ -338,6 +338,121 @@ __global__ void __launch_bounds__(256) k_trace(DScene sc, const float4* __restri
 #include "trace_oct.hpp"
 namespace rtmi {
 
+
+// ---------------------------------------------------------------- linear-list closest hit (root box is a leaf)
+// build_trivial_bounding_box (raytrace.rs:847-856): every ray scans the same list, so the list is
+// streamed ONCE per 256 rays through LDS in chunks of RTMI_LIN_CHUNK triangles (coalesced float4 gathers
+// by the whole block, double-buffered against the tests) and every lane reads the records at a
+// wave-uniform LDS address (broadcast).  Fold and test exactly as get_box_min_time_intersection /
+// Triangle::intersects (raytrace.rs:1012-1050, 400-439).
+#define RTMI_LIN_CHUNK 64
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_trace_linear(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
+                                                      DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
+                                                      float* __restrict__ hit_t) {
+    constexpr int C = RTMI_LIN_CHUNK;
+    __shared__ float4 rec[2][6][C];   // [buffer][plane0, plane1, edge0..3][triangle]
+    __shared__ uint32_t rid[2][C];
+    __shared__ uint32_t s_base;
+    const int tid = threadIdx.x;
+    const uint32_t count = ctrl->count[pass];
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctrl->rays, (unsigned long long)count);
+    const DNode root = sc.nodes[0];
+    const uint32_t first = root.first, ntri = root.count;
+    const uint32_t nchunks = (ntri + C - 1) / C;
+    unsigned long long cnt[5] = {0, 0, 0, 0, 0};
+    // staging: slot s of a chunk = float4 number (s / C) of triangle (s % C); 6*C slots, 256 threads
+    auto stage_load = [&](uint32_t chunk, float4 (&v)[2], uint32_t (&id)[2]) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t s = tid + k * 256;
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            id[k] = 0;
+            if (s < 6 * C) {
+                const uint32_t j = chunk * C + (s % C), c = s / C;
+                if (j < ntri) {
+                    const uint32_t t = sc.refs[first + j];
+                    id[k] = t;
+                    v[k] = c < 2 ? sc.tplane[2 * t + c] : sc.tedge[4 * t + (c - 2)];
+                }
+            }
+        }
+    };
+    auto stage_store = [&](int buf, const float4 (&v)[2], const uint32_t (&id)[2]) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t s = tid + k * 256;
+            if (s < 6 * C) {
+                rec[buf][s / C][s % C] = v[k];
+                if (s < C) rid[buf][s] = id[k];
+            }
+        }
+    };
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_base = atomicAdd(&ctrl->head[pass], 256u);
+        __syncthreads();
+        const uint32_t base = s_base;
+        if (base >= count) break;
+        const uint32_t i = base + tid;
+        const bool active = i < count;
+        const RayK r = active ? make_rayk(qo[i], qd[i]) : make_rayk(make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 1.f, 0.f));
+        bool lhave = false;
+        float lt = 0.f;
+        uint32_t ltf = 0;
+        float4 v[2];
+        uint32_t id[2];
+        if (nchunks) { stage_load(0, v, id); stage_store(0, v, id); }
+        __syncthreads();
+        for (uint32_t ch = 0; ch < nchunks; ch++) {
+            const int buf = ch & 1;
+            const bool next = ch + 1 < nchunks;
+            if (next) stage_load(ch + 1, v, id);  // global gathers in flight while this chunk is tested
+            const uint32_t n = min((uint32_t)C, ntri - ch * C);
+            for (uint32_t j = 0; j < n; j++) {
+                const float4 p0 = rec[buf][0][j], p1 = rec[buf][1][j];
+                const float ax = p0.x - r.ox, ay = p0.y - r.oy, az = p0.z - r.oz;
+                const float num = (((0.f + p1.x * ax) + p1.y * ay) + p1.z * az) + r.qn;
+                const float den = (((0.f + p1.x * r.dx) + p1.y * r.dy) + p1.z * r.dz) + r.qd;
+                const float t = num / den;
+                if (!(t < 0.f)) {
+                    const float px = r.dx * t + r.ox, py = r.dy * t + r.oy, pz = r.dz * t + r.oz, pw = r.dw * t + r.ow;
+                    const float ix = px - p0.x, iy = py - p0.y, iz = pz - p0.z;
+                    const float l2 = ((ix * ix + iy * iy) + iz * iz) + pw * pw;
+                    if (!(l2 > p0.w)) {
+                        if (COUNT && active) cnt[2]++;
+                        const float4 e0 = rec[buf][2][j], e1 = rec[buf][3][j], e2 = rec[buf][4][j], e3 = rec[buf][5][j];
+                        const float z = pw * 0.f;
+                        const float d0 = ((ix * e0.x + iy * e0.y) + iz * e0.z) + z;
+                        const float d1 = ((ix * e1.x + iy * e1.y) + iz * e1.z) + z;
+                        const float d2 = ((ix * e2.x + iy * e2.y) + iz * e2.z) + z;
+                        const bool inside = !(d0 > e0.w) & !(d1 > e1.w) & !(d2 > e2.w);
+                        const bool edge = (d0 > e3.x) | (d1 > e3.y) | (d2 > e3.z);
+                        const uint32_t face = (den > 0.f ? 1u : 0u) | (edge ? 2u : 0u);
+                        const bool take = inside & (!lhave | (t < lt));
+                        lt = take ? t : lt;
+                        ltf = take ? (rid[buf][j] | (face << 30)) : ltf;
+                        lhave = lhave | inside;
+                    }
+                }
+            }
+            if (COUNT && active) cnt[1] += n;
+            if (next) stage_store(buf ^ 1, v, id);
+            __syncthreads();
+        }
+        if (active) {
+            if (COUNT) cnt[4]++;
+            hit_tf[i] = lhave ? ltf : 0u;
+            hit_t[i] = lhave ? lt : 0.f;
+        }
+    }
+    if (COUNT) {
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (cnt[k]) atomicAdd(&ctrl->counters[k], cnt[k]);
+    }
+}
+
 // ---------------------------------------------------------------- generation / shading
 struct RayV { V4 orig, dir; };
 // make_ray (raytrace.rs:201-210); inv_dir is recomputed by the trace kernel
@@ -550,6 +665,7 @@ struct rtmi_scene {
     DevBuf<uint32_t> refs;
     DevBuf<float4> tplane, tedge, mats, onodes;
     DevBuf<uint4> oblocks;
+    bool root_is_leaf = false; // build_trivial_bounding_box: one list for every ray -> k_trace_linear
     bool octree = false;       // the tree passed the exact-octree check
     std::string why_generic;   // reason when it did not
     int oct_blocks_per_cu = 8;
@@ -738,6 +854,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     if (e == hipSuccess) e = up(s->tedge, he);
     if (e == hipSuccess) e = up(s->mats, hm);
     s->octree = !hon.empty();
+    s->root_is_leaf = boxes[0].is_leaf != 0;
     s->why_generic = why;
     if (e == hipSuccess && s->octree) e = up(s->onodes, hon);
     if (e == hipSuccess && s->octree) e = up(s->oblocks, hob);
@@ -806,11 +923,16 @@ static int ensure_workspace(rtmi_scene* s, size_t cap, uint32_t maxdepth) {
 extern "C++" {
 template <bool COUNT>
 static void launch_trace(rtmi_scene* s, hipStream_t st, const float4* qo, const float4* qd, int pass) {
+    if (s->root_is_leaf && !(s->options & RTMI_OPT_GENERIC)) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_linear<COUNT>), dim3((unsigned)(s->num_cu * 8)), dim3(256), 0, st, s->d, qo, qd,
+                           s->ctrl.p, pass, s->hit_tf.p, s->hit_t.p);
+        return;
+    }
     if (s->octree && !(s->options & RTMI_OPT_GENERIC)) {
         const int per_cu = (int)env_size("RTMI_OCT_WAVES_PER_CU", (size_t)s->oct_blocks_per_cu);
         dim3 grid((unsigned)(s->num_cu * per_cu)), block(64);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT>), grid, block, s->oct_lds, st, s->d, qo, qd, s->ctrl.p, pass,
-                           s->hit_tf.p, s->hit_t.p, s->redo.p);
+                           s->hit_tf.p, s->hit_t.p, s->redo.p, (int)env_size("RTMI_REFILL_MIN", 40));
         // exact re-trace of the (normally zero) rays whose leaf results contained a NaN hit time
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<false>), dim3(16), dim3((unsigned)s->trace_block), s->trace_lds, st, s->d, qo, qd,
                            s->ctrl.p, pass, s->hit_tf.p, s->hit_t.p, (const uint32_t*)s->redo.p);

@@ -120,7 +120,7 @@ __device__ inline void omerge(OFrame& f, bool have, float t) {
 template <bool COUNT>
 __global__ void __launch_bounds__(64, 6) k_trace_oct(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
                                                   DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
-                                                  float* __restrict__ hit_t, uint32_t* __restrict__ redo) {
+                                                  float* __restrict__ hit_t, uint32_t* __restrict__ redo, int refill_min) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;  // one wave per block
     constexpr int NT = 64;
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(64, 6) k_trace_oct(DScene sc, const float4* __
     for (;;) {
         const unsigned long long m_idle = __ballot(mode == M_IDLE);
         if (m_idle == ~0ull && exhausted) break;
-        if (!exhausted && (__popcll(m_idle) >= RTMI_REFILL_MIN || m_idle == ~0ull)) {
+        if (!exhausted && (__popcll(m_idle) >= refill_min || m_idle == ~0ull)) {
             // ---- refill: idle lanes take consecutive queued rays
             const uint32_t n = (uint32_t)__popcll(m_idle);
             if (COUNT && lane == 0) { dbg[4]++; dbg[5] += n; }

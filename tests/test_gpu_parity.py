@@ -138,12 +138,38 @@ def test_render_circles_seeded(circles_pair):
     assert_bits_equal(ref, img, "image")
 
 
-def test_render_linear_list_config2_small():
-    # BASELINE config 2 shape: teapot.obj, trivial bounding box (one leaf = linear list), reduced size
+@pytest.mark.parametrize("generic", [False, True])
+def test_render_linear_list_config2_small(generic):
+    # BASELINE config 2 shape: teapot.obj, trivial bounding box (one leaf = linear list), reduced size.
+    # generic=False runs the LDS-streamed k_trace_linear, True the generic-tree kernel on the same scene.
+    R = _R()
     pair = build_pair(recipe_canonical(accel="trivial", obj=TEAPOT))
-    ref, cn, img, ctx = _render_both(pair, 32, 32, 5, 2)
+    ref, cn, img, ctx = _render_both(pair, 33, 31, 5, 2, options=R.OPT_COUNTERS | (R.OPT_GENERIC if generic else 0))
     assert_bits_equal(ref, img, "image")
-    assert ctx.total_rays == cn["rays"]
+    for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
+        assert ctx.stats[k] == cn[k], k
+    assert cn["tri_tests"] == 6720 * cn["rays"]
+
+
+def test_trace_linear_list_edge_rays():
+    # the axis-aligned scene as ONE list: NaN / inf hit times and exact ties through k_trace_linear
+    from conftest import OracleApi, ProductApi
+    orc, R = _orc(), _R()
+
+    def relist(api):
+        s = recipe_axis_box()(api)
+        s.build_trivial_bounding_box([0.0, 0.0, 4.0], 4.0)
+        return s
+    so, sp = relist(OracleApi(orc)), relist(ProductApi(R))
+    rng = np.random.default_rng(3)
+    n = 700  # not a multiple of 256: ragged last block
+    o4 = np.zeros((n, 4), np.float32)
+    d4 = np.zeros((n, 4), np.float32)
+    o4[:, :3] = rng.integers(-2, 3, (n, 3)) * 0.5 + np.array([0, 0, 4])
+    d = rng.integers(-1, 2, (n, 3)).astype(np.float32)
+    d[(d == 0).all(axis=1)] = [0, 0, 1]
+    d4[:, :3] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    _compare_hits(so, sp, o4, d4)
 
 
 def test_render_axis_aligned_scene():
