@@ -932,7 +932,7 @@ static void launch_trace(rtmi_scene* s, hipStream_t st, const float4* qo, const 
         const int per_cu = (int)env_size("RTMI_OCT_WAVES_PER_CU", (size_t)s->oct_blocks_per_cu);
         dim3 grid((unsigned)(s->num_cu * per_cu)), block(64);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT>), grid, block, s->oct_lds, st, s->d, qo, qd, s->ctrl.p, pass,
-                           s->hit_tf.p, s->hit_t.p, s->redo.p, (int)env_size("RTMI_REFILL_MIN", 40));
+                           s->hit_tf.p, s->hit_t.p, s->redo.p, (int)(pass == 0 ? env_size("RTMI_REFILL_MIN0", 64) : env_size("RTMI_REFILL_MIN", 8)));
         // exact re-trace of the (normally zero) rays whose leaf results contained a NaN hit time
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<false>), dim3(16), dim3((unsigned)s->trace_block), s->trace_lds, st, s->d, qo, qd,
                            s->ctrl.p, pass, s->hit_tf.p, s->hit_t.p, (const uint32_t*)s->redo.p);
