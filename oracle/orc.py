@@ -156,6 +156,12 @@ class Scene:
         lib().orc_tree_flatten(self.h, _p(geo), _p(topo), _p(refs))
         return geo, topo, refs[: int(nrefs.value)]
 
+    def set_tree(self, geo, topo, refs):
+        geo = _f(geo).reshape(-1, 4)
+        topo = np.ascontiguousarray(topo, np.uint32).reshape(-1, 4)
+        refs = np.ascontiguousarray(refs, np.uint32)
+        self._check(lib().orc_set_tree(self.h, _p(geo), _p(topo), _p(refs), C.c_uint64(geo.shape[0]), C.c_uint64(refs.shape[0])))
+
     def render(self, w, h, vp12, maxdepth, spp, seed=1, row0=0, nrows=None, threads=1):
         nrows = h - row0 if nrows is None else nrows
         out = np.zeros((nrows, w, 4), np.float32)

@@ -1,0 +1,181 @@
+"""-m gpu: the C ABI called directly (ctypes on include/rtmi.h structs): hand-made trees, error codes,
+and the generic-tree kernel on trees that are NOT octrees, against the oracle running the same tree."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import OracleApi, assert_bits_equal, recipe_axis_box, recipe_circles
+
+pytestmark = pytest.mark.gpu
+
+RTMI_OK, RTMI_ERR_INVALID, RTMI_ERR_NO_DEVICE, RTMI_ERR_UNSUPPORTED = 0, 1, 2, 3
+
+
+class Tri(C.Structure):
+    _fields_ = [("incenter", C.c_float * 3), ("norm", C.c_float * 3), ("bounding_r2", C.c_float), ("sides", (C.c_float * 3) * 3),
+                ("side_lens", C.c_float * 3), ("edge_thickness", C.c_float), ("surface_kind", C.c_uint32), ("color", C.c_float * 3),
+                ("alpha", C.c_float), ("scattering", C.c_float)]
+
+
+class Box(C.Structure):
+    _fields_ = [("orig", C.c_float * 3), ("len2", C.c_float), ("first", C.c_uint32), ("count", C.c_uint32), ("is_leaf", C.c_uint32),
+                ("depth", C.c_uint32)]
+
+
+class Vp(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("orig", C.c_float * 3), ("cam", C.c_float * 3), ("vu", C.c_float * 3),
+                ("vv", C.c_float * 3), ("maxdepth", C.c_uint32), ("samples_per_pixel", C.c_uint32)]
+
+
+def _lib():
+    from rust_raytrace_amd import _ffi
+    L = _ffi.lib()
+    L.rtmi_scene_create.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+    L.rtmi_scene_destroy.argtypes = [C.c_void_p]
+    L.rtmi_scene_set_options.argtypes = [C.c_void_p, C.c_uint32]
+    L.rtmi_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.rtmi_trace.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return L, _ffi
+
+
+def _abi_arrays(oscene):
+    """rtmi_triangle_t[] / rtmi_box_t[] / refs from an oracle scene (records are 29 floats, see orc_get_triangles)."""
+    rec, kinds, surf = oscene.triangles()
+    tris = (Tri * len(rec))()
+    for i in range(len(rec)):
+        t = tris[i]
+        t.incenter[:] = rec[i, 0:3]; t.norm[:] = rec[i, 3:6]; t.bounding_r2 = rec[i, 6]
+        for k in range(3):
+            t.sides[k][:] = rec[i, 7 + 3 * k:10 + 3 * k]
+        t.side_lens[:] = rec[i, 16:19]; t.edge_thickness = rec[i, 19]
+        t.surface_kind = int(kinds[i]); t.color[:] = surf[i, 0:3]; t.alpha = surf[i, 3]; t.scattering = surf[i, 4]
+    geo, topo, refs = oscene.tree_flatten()
+    return tris, geo, topo, refs
+
+
+def _boxes(geo, topo):
+    boxes = (Box * len(geo))()
+    for i in range(len(geo)):
+        boxes[i].orig[:] = geo[i, 0:3]; boxes[i].len2 = geo[i, 3]
+        boxes[i].first, boxes[i].count, boxes[i].is_leaf, boxes[i].depth = (int(x) for x in topo[i])
+    return boxes
+
+
+def _create(L, tris, boxes, refs):
+    h = C.c_void_p()
+    refs = np.ascontiguousarray(refs, np.uint32)
+    rc = L.rtmi_scene_create(tris, len(tris), boxes, len(boxes), refs.ctypes.data_as(C.c_void_p), len(refs), 0, C.byref(h))
+    return rc, h
+
+
+def _render(L, ffi, h, vp12, w, hgt, maxdepth, spp, seed):
+    vp = Vp(w, hgt, (C.c_float * 3)(*vp12[0:3]), (C.c_float * 3)(*vp12[3:6]), (C.c_float * 3)(*vp12[6:9]), (C.c_float * 3)(*vp12[9:12]),
+            maxdepth, spp)
+    out = np.zeros((hgt, w, 4), np.float32)
+    st = ffi.Stats()
+    rc = L.rtmi_render(h, C.byref(vp), seed, 0, hgt, out.ctypes.data_as(C.c_void_p), C.byref(st))
+    assert rc == RTMI_OK, L.rtmi_last_error()
+    return out, st
+
+
+def test_non_octree_tree_runs_the_generic_kernel():
+    from oracle import orc
+    L, ffi = _lib()
+    so = recipe_circles(maxdepth=4, minobjs=6)(OracleApi(orc))
+    tris, geo, topo, refs = _abi_arrays(so)
+    # make it a NON-octree: nudge every box centre and grow every box a little (still encloses what it did)
+    rng = np.random.default_rng(5)
+    geo = geo.copy()
+    geo[:, 0:3] += rng.uniform(-0.01, 0.01, (len(geo), 3)).astype(np.float32)
+    geo[:, 3] *= np.float32(1.07)
+    so.set_tree(geo, topo, refs)
+    rc, h = _create(L, tris, _boxes(geo, topo), refs)
+    assert rc == RTMI_OK, L.rtmi_last_error()
+    try:
+        L.rtmi_scene_set_options(h, 1)  # RTMI_OPT_COUNTERS
+        vp12 = orc.canonical_viewport(40, 40)
+        img, st = _render(L, ffi, h, vp12, 40, 40, 5, 3, 17)
+        ref, cn = so.render(40, 40, vp12, 5, 3, seed=17, threads=8)
+        assert_bits_equal(ref, img, "image")
+        for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
+            assert getattr(st, k) == cn[k], k
+    finally:
+        L.rtmi_scene_destroy(h)
+
+
+def test_overlapping_two_child_tree():
+    # a hand-made tree: root with two overlapping children that both list every triangle (hits tie between leaves)
+    from oracle import orc
+    L, ffi = _lib()
+    so = recipe_axis_box()(OracleApi(orc))
+    tris, _, _, _ = _abi_arrays(so)
+    n = len(tris)
+    all_refs = np.arange(1, n, dtype=np.uint32)
+    geo = np.array([[0, 0, 4, 4], [-0.5, 0, 4, 3], [0.5, 0.25, 4.25, 3]], np.float32)
+    topo = np.array([[1, 2, 0, 0], [0, n - 1, 1, 1], [n - 1, n - 1, 1, 1]], np.uint32)
+    refs = np.concatenate([all_refs, all_refs[::-1]])  # second leaf lists them in reverse order
+    so.set_tree(geo, topo, refs)
+    rc, h = _create(L, tris, _boxes(geo, topo), refs)
+    assert rc == RTMI_OK, L.rtmi_last_error()
+    try:
+        vp12 = orc.create_viewport(31, 31, (1.0, 1.0), [0.0, 0.0, 0.0], orc.unit([0.0, 0.0, 1.0]), 90.0, 0.0)
+        img, st = _render(L, ffi, h, vp12, 31, 31, 4, 2, 3)
+        ref, cn = so.render(31, 31, vp12, 4, 2, seed=3, threads=4)
+        assert_bits_equal(ref, img, "image")
+        assert st.rays == cn["rays"]
+    finally:
+        L.rtmi_scene_destroy(h)
+
+
+def test_scene_create_rejects_malformed_input():
+    from oracle import orc
+    L, ffi = _lib()
+    so = recipe_axis_box()(OracleApi(orc))
+    tris, geo, topo, refs = _abi_arrays(so)
+
+    def expect(code, geo=geo, topo=topo, refs=refs, tris=tris, frag=None):
+        rc, h = _create(L, tris, _boxes(geo, topo), refs)
+        msg = L.rtmi_last_error().decode()
+        if rc == RTMI_OK:
+            L.rtmi_scene_destroy(h)
+        assert rc == code, (rc, msg)
+        if frag:
+            assert frag in msg, msg
+
+    bad = topo.copy(); bad[0, 0] = 0                     # root's child range starts at the root itself
+    expect(RTMI_ERR_INVALID, topo=bad, frag="follow")
+    bad = topo.copy(); bad[0, 1] = 9                     # nine children: the reference's boxmap has 8 slots
+    expect(RTMI_ERR_INVALID, topo=bad, frag="1..8")
+    leaf = int(np.nonzero(topo[:, 2] == 1)[0][0])
+    bad = topo.copy(); bad[leaf, 1] = len(refs) + 5      # leaf list runs past the reference array
+    expect(RTMI_ERR_INVALID, topo=bad, frag="out of bounds")
+    badr = refs.copy(); badr[0] = len(tris) + 3          # triangle index out of range
+    expect(RTMI_ERR_INVALID, refs=badr, frag="out of range")
+    t2 = (Tri * len(tris))(); C.memmove(t2, tris, C.sizeof(tris)); t2[1].surface_kind = 7
+    expect(RTMI_ERR_INVALID, tris=t2, frag="surface kind")
+    h = C.c_void_p()
+    assert L.rtmi_scene_create(None, 0, None, 0, None, 0, 0, C.byref(h)) == RTMI_ERR_INVALID
+    assert L.rtmi_scene_create(tris, len(tris), _boxes(geo, topo), len(geo), refs.ctypes.data_as(C.c_void_p), len(refs), 99,
+                               C.byref(h)) == RTMI_ERR_INVALID  # no such device
+    # a leaf that lists the sentinel triangle 0 is legal for the generic kernel (hit index 0 then reads as a miss)
+    z = refs.copy(); z[0] = 0
+    rc, h = _create(L, tris, _boxes(geo, topo), z)
+    assert rc == RTMI_OK
+    L.rtmi_scene_destroy(h)
+
+
+def test_trace_empty_and_null_arguments():
+    from oracle import orc
+    L, ffi = _lib()
+    so = recipe_axis_box()(OracleApi(orc))
+    tris, geo, topo, refs = _abi_arrays(so)
+    rc, h = _create(L, tris, _boxes(geo, topo), refs)
+    assert rc == RTMI_OK
+    try:
+        assert L.rtmi_trace(h, 0, None, None, None, None, None, None) == RTMI_OK          # empty input
+        assert L.rtmi_trace(h, 4, None, None, None, None, None, None) == RTMI_ERR_INVALID  # NULL buffers
+        assert L.rtmi_trace(None, 0, None, None, None, None, None, None) == RTMI_ERR_INVALID
+        assert b"NULL" in L.rtmi_last_error() or b"scene" in L.rtmi_last_error()
+    finally:
+        L.rtmi_scene_destroy(h)

@@ -324,3 +324,48 @@ def test_render_grid_config5_reduced():
     assert_bits_equal(ref, img, "image")
     for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
         assert ctx.stats[k] == cn[k], k
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_triangle_soups(seed):
+    """Random scenes: triangle soup with random surfaces and edge thickness, random octree parameters and camera.
+    Exercises boxes with many colliding children, leaves of all sizes, deep and shallow trees."""
+    from conftest import OracleApi, ProductApi
+    orc, R = _orc(), _R()
+    rng = np.random.default_rng(1000 + seed)
+    ntri = int(rng.integers(40, 400))
+    centre = rng.uniform(-3, 3, (ntri, 3)) + np.array([0, 0, 8.0])
+    pts = (centre[:, None, :] + rng.normal(scale=rng.uniform(0.2, 1.2), size=(ntri, 3, 3))).astype(np.float32)
+    kinds = rng.integers(0, 3, ntri)
+    cols = rng.integers(0, 256, (ntri, 3))
+    alphas = rng.uniform(0.05, 0.95, ntri)
+    scat = rng.uniform(0.0, 0.3, ntri)
+    edges = rng.choice([0.0, 0.05, 0.3, -1.0], ntri)
+    maxdepth, minobjs = int(rng.integers(2, 9)), int(rng.integers(2, 24))
+
+    def recipe(api):
+        s = api.scene()
+        for i in range(ntri):
+            c = tuple(int(x) for x in cols[i])
+            surf = (api.solid(c), api.matte(c, float(alphas[i])), api.reflective(float(scat[i]), c, float(alphas[i])))[kinds[i]]
+            try:
+                api.add_triangle(s, pts[i], surf, float(edges[i]))
+            except RuntimeError:
+                pass  # degenerate triangle: rejected identically by both implementations
+        s.populate_triangle_numbers()
+        s.build_bounding_box([0.0, 0.0, 8.0], 8.0, maxdepth, minobjs)
+        return s
+    so, sp = recipe(OracleApi(orc)), recipe(ProductApi(R))
+    assert so.num_tris() == sp.num_tris()
+    pos = rng.uniform(-1, 1, 3).astype(np.float32)
+    direction = orc.unit([float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)), 1.0])
+    w, h, spp, depth = 40, 28, int(rng.integers(1, 5)), int(rng.integers(1, 7))
+    vo = orc.create_viewport(w, h, (1.0, 0.7), pos, direction, 75.0, 0.1)
+    vp = R.create_viewport((w, h), (1.0, 0.7), pos, R.unit(direction), 75.0, 0.1, depth, spp)
+    assert_bits_equal(vo, vp.vp12, "viewport")
+    ref, cn = so.render(w, h, vo, depth, spp, seed=seed, threads=8)
+    img = np.zeros((h, w, 4), np.float32)
+    ctx = R.HipRayCaster(seed=seed, options=R.OPT_COUNTERS).walk_rays(vp, sp, img, 1, False)
+    assert_bits_equal(ref, img, f"image (ntri {ntri}, octree ({maxdepth},{minobjs}), spp {spp}, depth {depth})")
+    for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
+        assert ctx.stats[k] == cn[k], k
