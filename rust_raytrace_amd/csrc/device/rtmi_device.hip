@@ -82,6 +82,7 @@ __device__ inline void tile_pixel(const DView& v, uint32_t lp, uint32_t& row, ui
 struct DCtrl {
     uint32_t count[RTMI_MAX_PASSES + 1];  // rays queued for pass k
     uint32_t head[RTMI_MAX_PASSES + 1];   // work-fetch cursor of pass k
+    uint32_t xhead[RTMI_MAX_PASSES + 1][8];  // octree kernel: one cursor per XCD range of the queue
     uint32_t redo[RTMI_MAX_PASSES + 1];   // rays of pass k the octree kernel hands to the generic kernel (NaN hit times)
     uint32_t redo_head[RTMI_MAX_PASSES + 1];
     unsigned long long rays;              // sum of count[] (the "Rays" statistic)
@@ -932,7 +933,8 @@ static void launch_trace(rtmi_scene* s, hipStream_t st, const float4* qo, const 
         const int per_cu = (int)env_size("RTMI_OCT_WAVES_PER_CU", (size_t)s->oct_blocks_per_cu);
         dim3 grid((unsigned)(s->num_cu * per_cu)), block(64);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT>), grid, block, s->oct_lds, st, s->d, qo, qd, s->ctrl.p, pass,
-                           s->hit_tf.p, s->hit_t.p, s->redo.p, (int)(pass == 0 ? env_size("RTMI_REFILL_MIN0", 64) : env_size("RTMI_REFILL_MIN", 8)));
+                           s->hit_tf.p, s->hit_t.p, s->redo.p, (int)(pass == 0 ? env_size("RTMI_REFILL_MIN0", 64) : env_size("RTMI_REFILL_MIN", 8)),
+                           (int)env_size("RTMI_XCD_AWARE", 1) % 3);  // 1 = ranges by XCC_ID, 2 = by blockIdx % 8, 3 -> 0 = one range
         // exact re-trace of the (normally zero) rays whose leaf results contained a NaN hit time
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<false>), dim3(16), dim3((unsigned)s->trace_block), s->trace_lds, st, s->d, qo, qd,
                            s->ctrl.p, pass, s->hit_tf.p, s->hit_t.p, (const uint32_t*)s->redo.p);

@@ -46,6 +46,19 @@ struct OFrame { uint32_t w0, w1; float t; };
 
 #define RTMI_REFILL_MIN 16
 
+// v_max3_f32 / v_min3_f32: max(max(a,b),c) with fmaxf's NaN rule (a NaN operand is ignored), one instruction
+// instead of the two v_max + canonicalising moves hipcc emits for nested fmaxf.
+__device__ inline float max3f(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ inline float min3f(float a, float b, float c) {
+    float d;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 template <bool COUNT>
 __device__ inline OFrame expand_oct(float cx, float cy, float cz, uint32_t link, float hc, const RayK& r,
                                     unsigned long long* cnt) {
@@ -53,35 +66,41 @@ __device__ inline OFrame expand_oct(float cx, float cy, float cz, uint32_t link,
     if (COUNT) { cnt[0] += __popc(mask); cnt[3]++; }
     // candidate planes per axis (child centres: builder's orig.add(off_vec))
     const float xl = cx + (-hc), xh = cx + hc, yl = cy + (-hc), yh = cy + hc, zl = cz + (-hc), zh = cz + hc;
-    const float bx = r.ix * hc, by = r.iy * hc, bz = r.iz * hc;  // tmp2 = inv_dir * len2
+    // t1s = tmp1 - tmp2, t2s = tmp1 + tmp2 with tmp2 = inv_dir * len2 (raytrace.rs:866-870); near/far swap when
+    // inv_dir <= 0.  With b = (inv_dir > 0 ? inv_dir : -inv_dir) * len2 the pair is (a - b, a + b) in both cases,
+    // bit for bit: negation is exact and x + y == x - (-y).
+    const bool px = r.ix > 0.f, py = r.iy > 0.f, pz = r.iz > 0.f;
+    const float bx = (px ? r.ix : -r.ix) * hc, by = (py ? r.iy : -r.iy) * hc, bz = (pz ? r.iz : -r.iz) * hc;
     const float axl = (xl - r.ox) * r.ix, axh = (xh - r.ox) * r.ix;
     const float ayl = (yl - r.oy) * r.iy, ayh = (yh - r.oy) * r.iy;
     const float azl = (zl - r.oz) * r.iz, azh = (zh - r.oz) * r.iz;
-    // (near, far) per candidate: t1s = tmp1 - tmp2, t2s = tmp1 + tmp2, swapped when inv_dir <= 0
-    const bool px = r.ix > 0.f, py = r.iy > 0.f, pz = r.iz > 0.f;
-    float nx[2], fx[2], ny[2], fy[2], nz[2], fz[2];
-    { const float a = axl - bx, b = axl + bx; nx[0] = px ? a : b; fx[0] = px ? b : a; }
-    { const float a = axh - bx, b = axh + bx; nx[1] = px ? a : b; fx[1] = px ? b : a; }
-    { const float a = ayl - by, b = ayl + by; ny[0] = py ? a : b; fy[0] = py ? b : a; }
-    { const float a = ayh - by, b = ayh + by; ny[1] = py ? a : b; fy[1] = py ? b : a; }
-    { const float a = azl - bz, b = azl + bz; nz[0] = pz ? a : b; fz[0] = pz ? b : a; }
-    { const float a = azh - bz, b = azh + bz; nz[1] = pz ? a : b; fz[1] = pz ? b : a; }
+    float nx[2] = {axl - bx, axh - bx}, fx[2] = {axl + bx, axh + bx};
+    float ny[2] = {ayl - by, ayh - by}, fy[2] = {ayl + by, ayh + by};
+    float nz[2] = {azl - bz, azh - bz}, fz[2] = {azl + bz, azh + bz};
     // a zero direction component skips its slab (raytrace.rs:872, :882, :892): axis 0 then leaves the
-    // initial (-MAX, MAX); for axes 1, 2 a NaN operand makes fmaxf/fminf return the running value.
-    if (!(r.dx != 0.f)) { nx[0] = nx[1] = -FLT_MAX; fx[0] = fx[1] = FLT_MAX; }
-    if (!(r.dy != 0.f)) { ny[0] = ny[1] = fy[0] = fy[1] = __uint_as_float(0x7FC00000u); }
-    if (!(r.dz != 0.f)) { nz[0] = nz[1] = fz[0] = fz[1] = __uint_as_float(0x7FC00000u); }
+    // initial (-MAX, MAX); for axes 1, 2 a NaN operand makes max3/min3 return the running value.  Rare:
+    // whole waves skip this block.
+    if (!(r.dx != 0.f) | !(r.dy != 0.f) | !(r.dz != 0.f)) {
+        if (!(r.dx != 0.f)) { nx[0] = nx[1] = -FLT_MAX; fx[0] = fx[1] = FLT_MAX; }
+        if (!(r.dy != 0.f)) { ny[0] = ny[1] = fy[0] = fy[1] = __uint_as_float(0x7FC00000u); }
+        if (!(r.dz != 0.f)) { nz[0] = nz[1] = fz[0] = fz[1] = __uint_as_float(0x7FC00000u); }
+    }
+    // Conservative any-tmin-is-MAX flag (raytrace.rs:986 only matters when a colliding tmin == f32::MAX): a
+    // child's tmin is the max of three of these six values, so it can only be MAX if one of them is >= MAX.  The
+    // flag merely enables the exact re-check at selection time, so over-approximating is harmless.
+    const bool anymax = max3f(max3f(nx[0], nx[1], ny[0]), max3f(ny[1], nz[0], nz[1]), -FLT_MAX) >= FLT_MAX;
     float tm[8];
-    bool anymax = false;
     uint32_t nh = 0;
+    const uint32_t inf_bits = 0x7F800000u;
 #pragma unroll
     for (int o = 0; o < 8; o++) {
-        const float tmin = fmaxf(fmaxf(nx[o & 1], ny[(o >> 1) & 1]), nz[o >> 2]);
-        const float tmax = fminf(fminf(fx[o & 1], fy[(o >> 1) & 1]), fz[o >> 2]);
-        const bool hit = ((mask >> o) & 1u) && (tmin < tmax);
-        tm[o] = hit ? tmin : INFINITY;  // a colliding tmin is never NaN (tmin < tmax held) and never +inf
-        anymax |= hit && (tmin == FLT_MAX);
-        nh += hit ? 1u : 0u;
+        const float tmin = max3f(nx[o & 1], ny[(o >> 1) & 1], nz[o >> 2]);
+        const float tmax = min3f(fx[o & 1], fy[(o >> 1) & 1], fz[o >> 2]);
+        const uint32_t sel = (tmin < tmax) ? __float_as_uint(tmin) : inf_bits;
+        // keep it only when the octant exists: exists_o is bit o of the child mask, spread to a full-width mask
+        const uint32_t ex = (uint32_t)__builtin_amdgcn_sbfe((int)mask, o, 1);
+        tm[o] = __uint_as_float((sel & ex) | (inf_bits & ~ex));  // a colliding tmin is never NaN and never +inf
+        nh += (tm[o] < INFINITY) ? 1u : 0u;
     }
     // Stable ascending order of the colliding children (insertion sort of raytrace.rs:941-947) as a
     // rank: child i goes after every j < i with tm[j] <= tm[i] and every k > i with tm[k] < tm[i].
@@ -99,9 +118,9 @@ __device__ inline OFrame expand_oct(float cx, float cy, float cz, uint32_t link,
     // non-colliding children (tm = +inf) rank last; their slots lie beyond `nh` and are never read
     uint32_t order = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t rank = A[i] + (uint32_t)(7 - i) - B[i];
-        order |= (uint32_t)i << (3u * rank);
+    for (int i = 1; i < 8; i++) {
+        const uint32_t rank3 = (A[i] - B[i]) * 3u + (uint32_t)(3 * (7 - i));
+        order |= (uint32_t)i << rank3;
     }
     OFrame f;
     f.w0 = link;
@@ -120,7 +139,7 @@ __device__ inline void omerge(OFrame& f, bool have, float t) {
 template <bool COUNT>
 __global__ void __launch_bounds__(64, 6) k_trace_oct(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
                                                   DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
-                                                  float* __restrict__ hit_t, uint32_t* __restrict__ redo, int refill_min) {
+                                                  float* __restrict__ hit_t, uint32_t* __restrict__ redo, int refill_min, int xcd_aware) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;  // one wave per block
     constexpr int NT = 64;
@@ -133,6 +152,10 @@ __global__ void __launch_bounds__(64, 6) k_trace_oct(DScene sc, const float4* __
 
     uint32_t mode = M_IDLE;
     bool exhausted = false;  // wave-uniform
+    // HW_REG_XCC_ID (id 20, bits 3:0): which XCD this wave runs on; only a locality hint
+    const uint32_t nranges = xcd_aware ? 8u : 1u;
+    const uint32_t home = xcd_aware == 1 ? (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) : (blockIdx.x & 7u);
+    uint32_t tries = 0;      // ranges this wave has seen exhausted (wave-uniform)
     RayK r = make_rayk(make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 1.f, 0.f));
     uint32_t ridx = 0;
     OFrame cur{0, 0, 0.f};
@@ -153,13 +176,24 @@ __global__ void __launch_bounds__(64, 6) k_trace_oct(DScene sc, const float4* __
             // ---- refill: idle lanes take consecutive queued rays
             const uint32_t n = (uint32_t)__popcll(m_idle);
             if (COUNT && lane == 0) { dbg[4]++; dbg[5] += n; }
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&ctrl->head[pass], n);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base + n >= count) exhausted = true;
+            // XCD-aware work fetch: the queue is cut into 8 contiguous ranges, one per XCD (each XCD has its own
+            // L2, so the waves of an XCD walk one image region and share its boxes/triangles there).  A wave pulls
+            // from the range of the XCD it runs on and moves to the next range when that one is exhausted, so the
+            // ranges only steer locality, never correctness or balance.
+            uint32_t base = 0, hi = 0;
+            for (;;) {
+                const uint32_t x = (home + tries) % nranges;
+                hi = (uint32_t)(((unsigned long long)count * (x + 1)) / nranges);
+                const uint32_t lo = (uint32_t)(((unsigned long long)count * x) / nranges);
+                if (lane == 0) base = lo + atomicAdd(&ctrl->xhead[pass][x], n);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base < hi) break;
+                if (++tries == nranges) { exhausted = true; break; }
+            }
+            if (exhausted) continue;
             if (mode == M_IDLE) {
                 const uint32_t i = base + (uint32_t)__popcll(m_idle & lt_mask);
-                if (i < count) {
+                if (i < hi) {
                     ridx = i;
                     r = make_rayk(qo[i], qd[i]);
                     // virtual frame whose only child is the root box (index 0): the root itself is never
