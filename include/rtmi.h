@@ -144,6 +144,15 @@ int rtmi_trace(rtmi_scene_t* scene, uint64_t n, const float* orig4, const float*
 
 /* (c * 255.) as u8 per channel, RGB (raytrace.rs:1468-1473). */
 int rtmi_quantize(rtmi_scene_t* scene, const float* rgba_host, uint64_t npixels, uint8_t* rgb_host);
+/* Same on device memory, enqueued on `hip_stream`: lets a rank hand 3 bytes per pixel to the gather instead of 16. */
+int rtmi_quantize_device(rtmi_scene_t* scene, const void* rgba_device, uint64_t npixels, void* rgb_device, void* hip_stream);
+
+/* `make_triangle` (raytrace.rs:340-383) for n triangles on the GPU: corners (9 floats each) -> the geometric fields
+ * of rtmi_triangle_t (incenter, norm, bounding_r2, sides, side_lens); edge_thickness and the surface fields are copied
+ * from `proto`.  Bit-identical to the host computation.  Fails with RTMI_ERR_INVALID, naming the first offender, where
+ * the reference panics on a degenerate triangle (unwrap at raytrace.rs:357). */
+int rtmi_make_triangles(int device, const float* corners9_host, uint64_t n, const rtmi_triangle_t* proto,
+                        rtmi_triangle_t* out_host);
 
 /* Message of the last error on the calling thread ("" if none). */
 const char* rtmi_last_error(void);

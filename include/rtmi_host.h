@@ -44,6 +44,9 @@ int rth_add_disk(rth_scene_t* s, const float* orig3, const float* norm3, float r
                  uint32_t side_kind, const float* side_color3, float side_alpha, float side_scattering, float edge);
 int rth_add_sphere(rth_scene_t* s, const float* orig3, float r, uint64_t num_lat, uint64_t num_lon,
                    uint32_t kind, const float* color3, float alpha, float scattering, float edge);
+/* n triangles at once through the GPU make_triangle kernel (rtmi_make_triangles) */
+int rth_add_triangles_gpu(rth_scene_t* s, const float* pts9, uint64_t n, uint32_t kind, const float* color3, float alpha,
+                          float scattering, float edge, int device);
 void rth_populate_triangle_numbers(rth_scene_t* s);
 
 /* build_bounding_box / build_trivial_bounding_box into Scene.boxes */
@@ -69,7 +72,8 @@ int rth_caster_walk_tile_device(rth_scene_t* s, uint32_t w, uint32_t h, const fl
                                 double* wall_seconds);
 int rth_caster_trace(rth_scene_t* s, uint64_t n, const float* orig4, const float* dir4, uint32_t* tri, float* t,
                      uint32_t* face, rtmi_stats_t* stats);
-int rth_caster_upload(rth_scene_t* s); /* make the scene resident now (otherwise on first use) */
+int rth_caster_upload(rth_scene_t* s);
+int rth_caster_quantize_device(rth_scene_t* s, const void* rgba_device, uint64_t npixels, void* rgb_device, void* hip_stream); /* make the scene resident now (otherwise on first use) */
 
 /* write_png's quantisation on the host (raytrace.rs:1468-1473) */
 void rth_quantize(const float* rgba, uint64_t npixels, uint8_t* rgb);

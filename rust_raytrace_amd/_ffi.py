@@ -72,6 +72,7 @@ def lib():
     L.rth_create_transform.argtypes = [vp, f32, vp]
     L.rth_create_viewport.argtypes = [u32, u32, f32, f32, vp, vp, f32, f32, vp]
     L.rth_add_triangle.argtypes = [vp, vp, u32, vp, f32, f32, f32]
+    L.rth_add_triangles_gpu.argtypes = [vp, vp, u64, u32, vp, f32, f32, f32, i32]
     L.rth_add_obj.argtypes = [vp, C.c_char_p, vp, f32, vp, u32, vp, f32, f32, f32]
     L.rth_add_disk.argtypes = [vp, vp, vp, f32, f32, u64, u32, vp, f32, f32, u32, vp, f32, f32, f32]
     L.rth_add_sphere.argtypes = [vp, vp, f32, u64, u64, u32, vp, f32, f32, f32]
@@ -88,6 +89,7 @@ def lib():
     L.rth_caster_walk_rows.argtypes = [vp, u32, u32, vp, u64, u64, u64, u64, vp, vp, vp]
     L.rth_caster_walk_rows_device.argtypes = [vp, u32, u32, vp, u64, u64, u64, u64, vp, vp, vp, vp]
     L.rth_caster_walk_tile_device.argtypes = [vp, u32, u32, vp, u64, u64, vp, vp, vp, vp, vp]
+    L.rth_caster_quantize_device.argtypes = [vp, vp, u64, vp, vp]
     L.rth_caster_trace.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
     L.rth_quantize.argtypes = [vp, u64, vp]
     _lib = L
@@ -96,10 +98,10 @@ def lib():
 
 # every symbol include/rtmi.h and include/rtmi_host.h declare
 RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_set_options", "rtmi_render",
-                "rtmi_render_device", "rtmi_render_tile_device", "rtmi_trace", "rtmi_quantize", "rtmi_last_error"]
+                "rtmi_render_device", "rtmi_render_tile_device", "rtmi_trace", "rtmi_quantize", "rtmi_quantize_device", "rtmi_make_triangles", "rtmi_last_error"]
 RTH_SYMBOLS = ["rth_last_error", "rth_make_color", "rth_unit", "rth_to_radians", "rth_create_transform",
-               "rth_create_viewport", "rth_scene_new", "rth_scene_free", "rth_num_tris", "rth_add_triangle", "rth_add_obj",
+               "rth_create_viewport", "rth_scene_new", "rth_scene_free", "rth_num_tris", "rth_add_triangle", "rth_add_triangles_gpu", "rth_add_obj",
                "rth_add_disk", "rth_add_sphere", "rth_populate_triangle_numbers", "rth_build_bounding_box",
                "rth_build_trivial_bounding_box", "rth_box_contains_polygon", "rth_face_contains_triangle",
                "rth_get_triangles", "rth_tree_sizes", "rth_tree_get", "rth_caster_config", "rth_caster_walk_rows",
-               "rth_caster_walk_rows_device", "rth_caster_walk_tile_device", "rth_caster_trace", "rth_caster_upload", "rth_quantize"]
+               "rth_caster_walk_rows_device", "rth_caster_walk_tile_device", "rth_caster_trace", "rth_caster_upload", "rth_caster_quantize_device", "rth_quantize"]

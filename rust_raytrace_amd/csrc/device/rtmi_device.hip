@@ -336,6 +336,7 @@ __global__ void __launch_bounds__(256) k_trace(DScene sc, const float4* __restri
 }
 
 }  // namespace rtmi
+#include "make_triangle.hpp"
 #include "trace_oct.hpp"
 namespace rtmi {
 
@@ -1133,6 +1134,54 @@ int rtmi_debug_counters(rtmi_scene_t* s, unsigned long long* out16) {
     DCtrl h;
     HIPCHK(hipMemcpy(&h, s->ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost));
     memcpy(out16, h.dbg, sizeof(h.dbg));
+    return RTMI_OK;
+}
+
+int rtmi_make_triangles(int device, const float* corners9_host, uint64_t n, const rtmi_triangle_t* proto, rtmi_triangle_t* out_host) {
+    if (n == 0) return RTMI_OK;
+    if (!corners9_host || !proto || !out_host) return fail(RTMI_ERR_INVALID, "NULL argument");
+    if (n >= (1ull << 30)) return fail(RTMI_ERR_UNSUPPORTED, "more than 2^30 triangles");
+    const int ndev = rtmi_device_count();
+    if (ndev <= 0) return fail(RTMI_ERR_NO_DEVICE, "no HIP device visible: the MI355X kernels cannot run (there is no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(RTMI_ERR_INVALID, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    DevBuf<float> dpts, dout;
+    DevBuf<uint32_t> dok;
+    auto cleanup = [&]() { dpts.release(); dout.release(); dok.release(); };
+    hipError_t e = dpts.ensure(n * 9);
+    if (e == hipSuccess) e = dout.ensure(n * 20);
+    if (e == hipSuccess) e = dok.ensure(n);
+    if (e == hipSuccess) e = hipMemcpy(dpts.p, corners9_host, n * 9 * sizeof(float), hipMemcpyHostToDevice);
+    std::vector<float> rec(n * 20);
+    std::vector<uint32_t> ok(n);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_make_triangles, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 2048)), dim3(256), 0, nullptr, (uint32_t)n,
+                           dpts.p, dout.p, dok.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(rec.data(), dout.p, n * 20 * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(ok.data(), dok.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RTMI_ERR_OOM : RTMI_ERR_NO_DEVICE, std::string("rtmi_make_triangles: ") + hipGetErrorString(e));
+    for (uint64_t i = 0; i < n; i++) {
+        if (!ok[i]) return fail(RTMI_ERR_INVALID, "make_triangle: degenerate triangle " + std::to_string(i) + " (the reference panics at raytrace.rs:357)");
+        rtmi_triangle_t t = *proto;
+        const float* o = rec.data() + i * 20;
+        memcpy(t.incenter, o, 12); memcpy(t.norm, o + 3, 12); t.bounding_r2 = o[6];
+        memcpy(t.sides, o + 7, 36); memcpy(t.side_lens, o + 16, 12);
+        out_host[i] = t;
+    }
+    return RTMI_OK;
+}
+
+int rtmi_quantize_device(rtmi_scene_t* s, const void* rgba_device, uint64_t npixels, void* rgb_device, void* hip_stream) {
+    if (!s) return fail(RTMI_ERR_INVALID, "scene is NULL");
+    if (npixels == 0) return RTMI_OK;
+    if (!rgba_device || !rgb_device) return fail(RTMI_ERR_INVALID, "NULL argument");
+    HIPCHK(hipSetDevice(s->device));
+    hipLaunchKernelGGL(k_quantize, dim3((unsigned)(s->num_cu * 8)), dim3(256), 0, (hipStream_t)hip_stream, (uint64_t)npixels,
+                       (const float4*)rgba_device, (uint8_t*)rgb_device);
+    HIPCHK(hipGetLastError());
     return RTMI_OK;
 }
 

@@ -91,6 +91,15 @@ int rth_add_sphere(rth_scene_t* s, const float* orig3, float r, uint64_t nlat, u
         s->scene.tris.insert(s->scene.tris.end(), t.begin(), t.end());
     });
 }
+int rth_add_triangles_gpu(rth_scene_t* s, const float* p, uint64_t n, uint32_t kind, const float* c, float alpha, float scat,
+                          float edge, int device) {
+    return guarded([&] {
+        std::vector<Vec3> corners(n * 3);
+        for (uint64_t i = 0; i < n * 3; i++) corners[i] = v3(p + 3 * i);
+        auto t = make_triangles_gpu(corners, surf(kind, c, alpha, scat), edge, device);
+        s->scene.tris.insert(s->scene.tris.end(), t.begin(), t.end());
+    });
+}
 void rth_populate_triangle_numbers(rth_scene_t* s) { populate_triangle_numbers(s->scene.tris); }
 
 int rth_build_bounding_box(rth_scene_t* s, const float* orig3, float len2, uint64_t maxdepth, uint64_t minobjs, uint32_t threads) {
@@ -188,6 +197,13 @@ int rth_caster_trace(rth_scene_t* s, uint64_t n, const float* o4, const float* d
         rtmi_scene_t* h = caster_of(s).resident(s->scene);
         if (rtmi_trace(h, n, o4, d4, tri, t, face, stats) != RTMI_OK)
             throw std::runtime_error(std::string("rtmi_trace: ") + rtmi_last_error());
+    });
+}
+
+int rth_caster_quantize_device(rth_scene_t* s, const void* rgba_device, uint64_t npixels, void* rgb_device, void* hip_stream) {
+    return guarded([&] {
+        if (rtmi_quantize_device(caster_of(s).resident(s->scene), rgba_device, npixels, rgb_device, hip_stream) != RTMI_OK)
+            throw std::runtime_error(std::string("rtmi_quantize_device: ") + rtmi_last_error());
     });
 }
 

@@ -108,6 +108,30 @@ Triangle make_triangle(const Vec3 (&points)[3], const SurfaceKind& surface, floa
     return t;
 }
 
+std::vector<Triangle> make_triangles_gpu(const std::vector<Vec3>& corners, const SurfaceKind& surface, float edge_thickness,
+                                         int device) {
+    if (corners.size() % 3 != 0) throw std::runtime_error("make_triangles_gpu: corners must come in threes");
+    const size_t n = corners.size() / 3;
+    std::vector<float> pts(n * 9);
+    for (size_t i = 0; i < corners.size(); i++) memcpy(&pts[i * 3], corners[i].v, 12);
+    rtmi_triangle_t proto{};
+    proto.edge_thickness = edge_thickness;
+    proto.surface_kind = surface.tag;
+    memcpy(proto.color, surface.color.v, 12);
+    proto.alpha = surface.alpha; proto.scattering = surface.scattering;
+    std::vector<rtmi_triangle_t> rec(n);
+    if (rtmi_make_triangles(device, pts.data(), n, &proto, rec.data()) != RTMI_OK)
+        throw std::runtime_error(std::string("rtmi_make_triangles: ") + rtmi_last_error());
+    std::vector<Triangle> out(n);
+    for (size_t i = 0; i < n; i++) {
+        Triangle& t = out[i];
+        t.incenter = make_vec(rec[i].incenter); t.norm = make_vec(rec[i].norm); t.bounding_r2 = rec[i].bounding_r2;
+        for (int k = 0; k < 3; k++) { t.sides[k] = make_vec(rec[i].sides[k]); t.side_lens[k] = rec[i].side_lens[k]; t.corners[k] = corners[3 * i + k]; }
+        t.surface = surface; t.edge_thickness = edge_thickness; t.num = 0;
+    }
+    return out;
+}
+
 Triangle make_dummy_triangle() {
     const Vec3 pts[3] = {make_vec(1.f, 0.f, 0.f), make_vec(0.f, 1.f, 0.f), make_vec(0.f, 0.f, 1.f)};
     return make_triangle(pts, SurfaceKind::solid(make_color(255, 0, 0)), 0.f);

@@ -71,6 +71,9 @@ struct Triangle {
 };
 
 Triangle make_triangle(const Vec3 (&points)[3], const SurfaceKind& surface, float edge_thickness);  // :340-383
+// The same for many triangles on the GPU (rtmi_make_triangles): corners[i] = 3 points; bit-identical results.
+std::vector<Triangle> make_triangles_gpu(const std::vector<Vec3>& corners, const SurfaceKind& surface, float edge_thickness,
+                                         int device = 0);
 Triangle make_dummy_triangle();                                                                      // :385-391
 void populate_triangle_numbers(std::vector<Triangle>& tris);                                         // :393-397
 std::vector<Triangle> make_sphere(const Point& orig, float r, std::pair<size_t, size_t> lat_lon,

@@ -46,21 +46,23 @@ def max_rows(world, height, stripe_rows=DEFAULT_STRIPE_ROWS):
 
 
 def gather_frame(local, rank, world, height, width, stripe_rows=DEFAULT_STRIPE_ROWS, dst=0, group=None):
-    """Collect the per-rank bands on `dst` and return the (H, W, 4) frame there (None elsewhere).
+    """Collect the per-rank bands on `dst` and return the (H, W, C) frame there (None elsewhere).
 
-    `local` is a torch tensor (rows_r, W, 4) f32 on the rank's device.  One
-    gather of equal-sized (padded) bands, then an index copy on the root."""
+    `local` is a torch tensor (rows_r, W, C) on the rank's device: C = 4 f32 (the reference's `[Color]`) or
+    C = 3 u8 (already quantised with HipRayCaster.quantize_device: 3 bytes per pixel over the links instead
+    of 16).  One gather of equal-sized (padded) bands, then an index copy on the root."""
     import torch
     import torch.distributed as dist
 
+    ch = local.shape[2]
     if world == 1:
-        frame = torch.empty((height, width, 4), dtype=local.dtype, device=local.device)
+        frame = torch.empty((height, width, ch), dtype=local.dtype, device=local.device)
         frame[torch.as_tensor(tile_rows_for(0, 1, height, stripe_rows), device=local.device)] = local
         return frame
     mr = max_rows(world, height, stripe_rows)
     send = local
     if local.shape[0] != mr:
-        send = torch.zeros((mr, width, 4), dtype=local.dtype, device=local.device)
+        send = torch.zeros((mr, width, ch), dtype=local.dtype, device=local.device)
         send[: local.shape[0]] = local
     send = send.contiguous()
     if dist.get_backend(group) == "gloo" and send.is_cuda:
@@ -69,7 +71,7 @@ def gather_frame(local, rank, world, height, width, stripe_rows=DEFAULT_STRIPE_R
     dist.gather(send, bands, dst=dst, group=group)
     if rank != dst:
         return None
-    frame = torch.empty((height, width, 4), dtype=local.dtype, device=local.device)
+    frame = torch.empty((height, width, ch), dtype=local.dtype, device=local.device)
     for r in range(world):
         rows = tile_rows_for(r, world, height, stripe_rows)
         frame[torch.as_tensor(rows, device=local.device)] = bands[r][: len(rows)].to(local.device)

@@ -111,6 +111,11 @@ class Scene:
         """obj_data.push(make_triangle(points, surface, edge_thickness))"""
         _chk(_ffi.lib().rth_add_triangle(self.h, _p(_f(points).reshape(9)), *surface.args(), edge_thickness))
 
+    def extend_make_triangles_gpu(self, points, surface, edge_thickness, device=0):
+        """obj_data.extend(points.map(make_triangle)) computed by the GPU kernel (rtmi_make_triangles); points: (n, 3, 3)."""
+        pts = _f(points).reshape(-1, 9)
+        _chk(_ffi.lib().rth_add_triangles_gpu(self.h, _p(pts), pts.shape[0], *surface.args(), edge_thickness, device))
+
     def extend_parse_obj(self, path, offset, scale, transform, surface, edge_thickness):
         """obj_data.extend(obj_parser::parse_obj(...)) — obj_parser.rs:47-73"""
         _chk(_ffi.lib().rth_add_obj(self.h, path.encode(), _p(_f(offset)), scale, _p(_f(transform)), *surface.args(),
@@ -227,6 +232,11 @@ class HipRayCaster:
                                                     C.byref(t), C.c_void_p(out_ptr), C.c_void_p(stream_ptr or 0),
                                                     C.byref(st), C.byref(wall)))
         return ProgressCtx(st.rays, wall.value, st.as_dict())
+
+    def quantize_device(self, s, rgba_ptr, npixels, rgb_ptr, stream_ptr=None):
+        """write_png's `(c * 255.) as u8` on device memory (f32x4 -> u8x3), enqueued on the stream."""
+        self._config(s)
+        _chk(_ffi.lib().rth_caster_quantize_device(s.h, C.c_void_p(rgba_ptr), npixels, C.c_void_p(rgb_ptr), C.c_void_p(stream_ptr or 0)))
 
     def upload(self, s):
         self._config(s)

@@ -21,6 +21,47 @@ def test_tiles_partition_the_image():
                     assert np.array_equal(rd.tile_rows(t, H), rd.tile_rows_for(r, world, H, S))
 
 
+def _worker_u8(rank, world, port, H, W, S, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from rust_raytrace_amd import dist as rd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows = rd.tile_rows_for(rank, world, H, S)
+    local = torch.zeros((len(rows), W, 3), dtype=torch.uint8)
+    for i, r in enumerate(rows):
+        local[i, :, 0] = int(r) % 251
+        local[i, :, 1] = (torch.arange(W) * 7 % 256).to(torch.uint8)
+        local[i, :, 2] = rank + 1
+    frame = rd.gather_frame(local, rank, world, H, W, S)
+    if rank == 0:
+        q.put(frame.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_quantised_bands_gloo_world2():
+    import torch.multiprocessing as mp
+    world, W, H, S = 2, 5, 37, 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_u8, args=(r, world, port, H, W, S, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    frame = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert frame.shape == (H, W, 3) and frame.dtype == np.uint8
+    assert np.array_equal(frame[:, 0, 0], (np.arange(H) % 251).astype(np.uint8))
+    assert np.array_equal(frame[:, 0, 2], ((np.arange(H) // S) % world + 1).astype(np.uint8))
+
+
 def _worker(rank, world, port, H, W, S, q):
     import torch
     import torch.distributed as dist

@@ -369,3 +369,35 @@ def test_random_triangle_soups(seed):
     assert_bits_equal(ref, img, f"image (ntri {ntri}, octree ({maxdepth},{minobjs}), spp {spp}, depth {depth})")
     for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
         assert ctx.stats[k] == cn[k], k
+
+
+def test_quantize_device_matches_oracle(canonical_pair):
+    import torch
+    R = _R()
+    _, sp = canonical_pair
+    H, W = 24, 40
+    vp = R.canonical_viewport(W, H, 5, 2)
+    c = R.HipRayCaster(seed=2)
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    c.walk_tile_device(vp, sp, (0, H, H, 0), frame.data_ptr(), st)
+    rgb = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0")
+    c.quantize_device(sp, frame.data_ptr(), H * W, rgb.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(rgb.cpu().numpy().reshape(-1, 3), _orc().quantize(frame.cpu().numpy()))
+
+
+def test_make_triangles_gpu(canonical_pair):
+    # the GPU make_triangle kernel against the host computation: every record of the canonical scene, bit for bit
+    R = _R()
+    _, sp = canonical_pair
+    rec, kinds, surf = sp.triangles()
+    s = R.Scene(False)
+    matte = R.SurfaceKind.Matte(R.make_color(252, 119, 0), 0.2)
+    s.extend_make_triangles_gpu(rec[:, 20:29].reshape(-1, 3, 3), matte, 0.05)
+    got, _, _ = s.triangles()
+    assert got.shape == rec.shape
+    assert_bits_equal(got[:, :19], rec[:, :19], "geometric fields")  # incenter norm r2 sides side_lens
+    assert_bits_equal(got[:, 20:], rec[:, 20:], "corners")
+    with pytest.raises(RuntimeError, match="degenerate triangle 1"):
+        s.extend_make_triangles_gpu(np.array([[[0, 0, 1], [1, 0, 1], [0, 1, 1]], [[0, 0, 0], [0, 0, 0], [0, 0, 0]]], np.float32), matte, 0.0)
