@@ -769,10 +769,13 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
                 if (!ok) break;
                 if (hob.size() >= (1ull << 24)) { ok = false; why = "more than 2^24 reference blocks"; break; }
                 link[i] = (uint32_t)hob.size();
-                for (uint32_t k = 0; k < b.count + 1; k += 4) {  // count refs + at least one terminating 0
+                // blocks of 4 indices; the list ends at the first 0, or after a block whose 4th index carries
+                // bit 31 (a full last block: no extra all-zero block, triangle indices are < 2^30)
+                for (uint32_t k = 0; k < std::max<uint32_t>(b.count, 1u); k += 4) {
                     uint32_t v[4] = {0, 0, 0, 0};
                     for (uint32_t j = 0; j < 4; j++)
                         if (k + j < b.count) v[j] = tri_refs[b.first + k + j];
+                    if (k + 4 == b.count) v[3] |= 0x80000000u;
                     hob.push_back(make_uint4(v[0], v[1], v[2], v[3]));
                 }
             } else {

@@ -27,9 +27,9 @@
 //             link = low 24 bits | child_mask << 24.  Inner: low = index of the
 //             first child, mask = octants present (children stored in octant
 //             order).  Leaf: mask = 0, low = index of its first reference block.
-//   oblocks : uint4 blocks of triangle indices of a leaf, in list order,
-//             terminated by index 0 (the sentinel triangle is never in a tree,
-//             raytrace.rs:791), always at least one 0 at the end.
+//   oblocks : uint4 blocks of triangle indices of a leaf, in list order.  The list ends at the first index 0
+//             (the sentinel triangle is never in a tree, raytrace.rs:791) or after a full block whose 4th
+//             index has bit 31 set.
 #pragma once
 
 namespace rtmi {
@@ -270,11 +270,11 @@ __global__ void __launch_bounds__(64, 6) k_trace_oct(DScene sc, const float4* __
         } else {
             // ================================================= LEAF step: one block of <= 4 references
             if (mode == M_LEAF) {
-                const uint32_t ids[4] = {blk.x, blk.y, blk.z, blk.w};
+                const uint32_t ids[4] = {blk.x, blk.y, blk.z, blk.w & 0x7FFFFFFFu};
                 float4 p0[4], p1[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) { p0[k] = sc.tplane[2 * ids[k]]; p1[k] = sc.tplane[2 * ids[k] + 1]; }
-                const bool more = blk.w != 0u;
+                const bool more = blk.w != 0u && !(blk.w >> 31);  // bit 31 of the 4th index: this full block is the last
                 if (more) { lblock++; blk = sc.oblocks[lblock]; }  // prefetch the next block
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
