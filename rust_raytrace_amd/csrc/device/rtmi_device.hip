@@ -1000,7 +1000,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
         return RTMI_OK;
     }
     // batch = whole pixels with all their samples
-    const size_t want_paths = env_size("RTMI_BATCH_PATHS", (size_t)128 << 20);
+    const size_t want_paths = env_size("RTMI_BATCH_PATHS", (size_t)256 << 20);
     uint64_t pix_per_batch = std::max<uint64_t>(1, want_paths / spp);
     pix_per_batch = std::min<uint64_t>(pix_per_batch, npix);
     if (pix_per_batch * spp >= (1ull << 31)) return fail(RTMI_ERR_UNSUPPORTED, "batch above 2^31 paths");
