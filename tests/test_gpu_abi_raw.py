@@ -179,3 +179,58 @@ def test_trace_empty_and_null_arguments():
         assert b"NULL" in L.rtmi_last_error() or b"scene" in L.rtmi_last_error()
     finally:
         L.rtmi_scene_destroy(h)
+
+
+@pytest.mark.parametrize("options", [0, 2])  # 2 = RTMI_OPT_GENERIC
+def test_deep_chain_tree(options):
+    """A hand-made exact octree 14 levels deep (the reference builder cannot make deep trees cheaply: every triangle is
+    listed in all boxes its plane crosses).  Each inner box has the octant containing P as its main child plus, on even
+    levels, the mirrored octant as a sibling leaf; exercises deep LDS stacks in the octree kernel and the 64-thread
+    blocks of the generic kernel."""
+    from oracle import orc
+    L, ffi = _lib()
+    so = recipe_axis_box()(OracleApi(orc))
+    tris, _, _, _ = _abi_arrays(so)
+    all_refs = list(range(1, len(tris)))
+    f32 = np.float32
+    P = np.array([0.3, 0.2, 4.4], f32)
+    depth = 14
+
+    def make(c, h, d):
+        if d == depth:
+            return dict(c=c, h=h, d=d, refs=all_refs)
+        hm = f32(h / f32(2.0))
+        main = np.array([f32(c[a] + (hm if P[a] >= c[a] else f32(-1.0) * hm)) for a in range(3)], f32)
+        kids = [make(main, hm, d + 1)]
+        if d % 2 == 0:
+            sib = np.array([f32(c[a] + (f32(-1.0) * hm if P[a] >= c[a] else hm)) for a in range(3)], f32)
+            kids.append(dict(c=sib, h=hm, d=d + 1, refs=all_refs[::2] if d % 4 == 0 else all_refs[1::2]))
+        kids.sort(key=lambda k: sum(1 << a for a in range(3) if k["c"][a] > c[a]))  # octant order
+        return dict(c=c, h=h, d=d, kids=kids)
+
+    root = make(np.array([0.0, 0.0, 4.0], f32), f32(4.0), 0)
+    geo, topo, refs, queue = [], [], [], [root]
+    for node in queue:  # breadth-first; the list grows while we walk it
+        geo.append([*node["c"], node["h"]])
+        if "refs" in node:
+            topo.append([len(refs), len(node["refs"]), 1, node["d"]])
+            refs += node["refs"]
+        else:
+            topo.append([len(queue), len(node["kids"]), 0, node["d"]])
+            queue += node["kids"]
+    geo = np.array(geo, f32); topo = np.array(topo, np.uint32); refs = np.array(refs, np.uint32)
+    assert topo[:, 3].max() == depth
+    so.set_tree(geo, topo, refs)
+    rc, h = _create(L, tris, _boxes(geo, topo), refs)
+    assert rc == RTMI_OK, L.rtmi_last_error()
+    try:
+        L.rtmi_scene_set_options(h, 1 | options)
+        vp12 = orc.create_viewport(29, 29, (1.0, 1.0), [0.0, 0.0, 0.0], orc.unit([0.0, 0.0, 1.0]), 90.0, 0.0)
+        img, st = _render(L, ffi, h, vp12, 29, 29, 5, 3, 12)
+        ref, cn = so.render(29, 29, vp12, 5, 3, seed=12, threads=4)
+        assert_bits_equal(ref, img, "image")
+        for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
+            assert getattr(st, k) == cn[k], k
+        assert cn["nodes"] > cn["rays"]  # the chain is really descended
+    finally:
+        L.rtmi_scene_destroy(h)

@@ -401,3 +401,17 @@ def test_make_triangles_gpu(canonical_pair):
     assert_bits_equal(got[:, 20:], rec[:, 20:], "corners")
     with pytest.raises(RuntimeError, match="degenerate triangle 1"):
         s.extend_make_triangles_gpu(np.array([[[0, 0, 1], [1, 0, 1], [0, 1, 1]], [[0, 0, 0], [0, 0, 0], [0, 0, 0]]], np.float32), matte, 0.0)
+
+
+def test_odd_sizes_and_many_samples(circles_pair):
+    so, sp = circles_pair
+    orc, R = _orc(), _R()
+    for (w, h, spp, depth) in ((1, 1, 1, 5), (17, 5, 3, 2), (3, 29, 65, 3), (64, 2, 130, 5)):
+        vo = orc.canonical_viewport(w, h)
+        vp = R.canonical_viewport(w, h, depth, spp)
+        assert_bits_equal(vo, vp.vp12, "viewport")
+        ref, cn = so.render(w, h, vo, depth, spp, seed=6, threads=8)
+        img = np.zeros((h, w, 4), np.float32)
+        ctx = R.HipRayCaster(seed=6).walk_rays(vp, sp, img, 1, False)
+        assert_bits_equal(ref, img, f"image {w}x{h}x{spp}")
+        assert ctx.total_rays == cn["rays"]
