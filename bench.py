@@ -150,12 +150,18 @@ def main():
                     traffic = json.load(open(pj)).get("k_trace_hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roofline = {"bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            nstreams = max(int(ctx.stats.get("streams", 1)), 1)
+            roofline = {"bound": "hbm", "kernel": "k_trace_oct" if args.scene != "linear" else "k_trace_linear",
+                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(avg_launch_ms, 3),
                         "bytes_per_ray": round(alg_bytes / max(st["rays"], 1), 1),
-                        "trace_share_of_kernel_time": round(trace_ms / max(kernel_ms, 1e-9), 3),
-                        "note": "served from L2/Infinity Cache (scene ~19 MB); VALU/latency-bound, see DESIGN.md"}
+                        "concurrent_launches": nstreams,
+                        "achieved_chip": round(achieved * nstreams, 1), "frac_chip": round(achieved * nstreams / HBM_PEAK_GBS, 4),
+                        "trace_share_of_kernel_time": round(trace_ms / max(kernel_ms * nstreams, 1e-9), 3),
+                        "note": "achieved = algorithmic bytes of ONE launch / its HIP-event duration; the library runs "
+                                f"{nstreams} such launches concurrently (two sub-tiles on two streams), so the chip-level rate is "
+                                "achieved_chip.  The records are served from L2/Infinity Cache (scene ~19 MB): VALU/latency-bound, see DESIGN.md"}
         if world == 1 and not args.no_cpu_baseline and args.scene == "canonical":
             from oracle import orc
             cw, ch, cspp = (int(x) for x in args.cpu_sample.split("x"))

@@ -77,10 +77,10 @@ typedef struct rtmi_viewport {
 typedef struct rtmi_stats {
     uint64_t rays;
     uint64_t box_tests, tri_tests, full_tests, nodes, leaves; /* filled only when counting is enabled */
-    double kernel_ms;  /* device time of the render kernels (HIP events)   */
-    double trace_ms;   /* of which: the closest-hit kernel                  */
+    double kernel_ms;  /* device time span of the call (HIP events on the caller's stream)               */
+    double trace_ms;   /* sum of the durations of the closest-hit launches (HIP events on their streams)  */
     uint32_t trace_launches;
-    uint32_t reserved;
+    uint32_t streams;  /* internal streams that ran concurrently (1 or 2): launches overlap when 2        */
 } rtmi_stats_t;
 
 /* A set of image rows: `nrows` rows taken in stripes of `stripe_rows`
@@ -122,6 +122,9 @@ int rtmi_scene_set_options(rtmi_scene_t* scene, uint32_t options);
  * rtmi_render writes host memory; rtmi_render_device writes device memory on
  * `hip_stream` (a hipStream_t, or NULL for the default stream) and returns
  * after the work is enqueued and the counters are read back. */
+/* Internally a tile is rendered as two interleaved sub-tiles on two HIP streams of the library (the small deep bounce
+ * passes of one overlap the bulk of the other); they start after the work already queued on `hip_stream` and that
+ * stream is made to wait for them. */
 int rtmi_render(rtmi_scene_t* scene, const rtmi_viewport_t* vp, uint64_t seed,
                 uint32_t row0, uint32_t nrows, float* out_host, rtmi_stats_t* stats);
 int rtmi_render_device(rtmi_scene_t* scene, const rtmi_viewport_t* vp, uint64_t seed,

@@ -17,10 +17,10 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("full_tests", C.c_uint64), ("nodes", C.c_uint64), ("leaves", C.c_uint64),
                 ("kernel_ms", C.c_double), ("trace_ms", C.c_double), ("trace_launches", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("streams", C.c_uint32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class Tile(C.Structure):

@@ -597,8 +597,11 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed
 }
 
 // walk_ray_set's per-pixel accumulation (raytrace.rs:1414-1426)
+// `out` is the caller's tile buffer; the sub-tile `sub` of `nsub` holds every nsub-th stripe (S rows) of that tile, so
+// local row lr of the sub-tile is row ((lr / S) * nsub + sub) * S + lr % S of the buffer.
 __global__ void __launch_bounds__(256) k_accum(uint32_t npixels, uint32_t spp, const float4* __restrict__ scol,
-                                               float4* __restrict__ out) {
+                                               float4* __restrict__ out, uint32_t pix0, uint32_t W, uint32_t S, uint32_t nsub,
+                                               uint32_t sub) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npixels; p += stride) {
         V4 acc = mk(0.f, 0.f, 0.f);
@@ -607,7 +610,10 @@ __global__ void __launch_bounds__(256) k_accum(uint32_t npixels, uint32_t spp, c
             acc = vadd(acc, V4{c.x, c.y, c.z, c.w});
         }
         const V4 px = vmul(acc, 1.f / (float)spp);
-        out[p] = make_float4(px.x, px.y, px.z, px.w);
+        const uint32_t lp = pix0 + p, lr = lp / W, col = lp - lr * W;
+        const uint32_t k = lr / S;
+        const size_t orow = (size_t)(k * nsub + sub) * S + (lr - k * S);
+        out[orow * W + col] = make_float4(px.x, px.y, px.z, px.w);
     }
 }
 
@@ -659,6 +665,27 @@ struct DevBuf {
 
 using namespace rtmi;
 
+// Per-stream workspace of one batch (queues, hit records, surface stacks, sample colours, control block).
+struct Work {
+    size_t cap = 0;
+    uint32_t cap_depth = 0;
+    DevBuf<float4> qo[2], qd[2], scol;
+    DevBuf<uint32_t> qpath[2], hit_tf, redo;
+    DevBuf<float> hit_t;
+    DevBuf<uint16_t> mstack;
+    DevBuf<DCtrl> ctrl;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> pass_ev;  // start/stop of the trace kernel of every pass
+    void release() {
+        for (int k = 0; k < 2; k++) { qo[k].release(); qd[k].release(); qpath[k].release(); }
+        scol.release(); hit_tf.release(); redo.release(); hit_t.release(); mstack.release(); ctrl.release();
+        for (int k = 0; k < 2; k++) if (ev[k]) { (void)hipEventDestroy(ev[k]); ev[k] = nullptr; }
+        for (hipEvent_t e : pass_ev) (void)hipEventDestroy(e);
+        pass_ev.clear();
+        cap = 0; cap_depth = 0;
+    }
+};
+
 struct rtmi_scene {
     int device = 0;
     uint32_t options = 0;
@@ -672,17 +699,13 @@ struct rtmi_scene {
     std::string why_generic;   // reason when it did not
     int oct_blocks_per_cu = 8;
     size_t oct_lds = 0;
-    // per-batch workspace
-    size_t cap = 0;
-    uint32_t cap_depth = 0;
-    DevBuf<float4> qo[2], qd[2], scol, tile;
-    DevBuf<uint32_t> qpath[2], hit_tf, redo;
-    DevBuf<float> hit_t;
-    DevBuf<uint16_t> mstack;
-    DevBuf<DCtrl> ctrl;
+    // A tile is rendered as up to two interleaved sub-tiles, each with its own workspace on its own internal
+    // stream, so that the small deep bounce passes of one overlap the bulk of the other.
+    Work w[2];
+    hipStream_t istream[2] = {nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, end_ev = nullptr, join_ev[2] = {nullptr, nullptr};
+    DevBuf<float4> tile;
     DevBuf<uint8_t> qbytes;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    std::vector<hipEvent_t> pass_ev;  // start/stop of the trace kernel of every pass
     int num_cu = 256;
     int trace_block = 256;
     size_t trace_lds = 0;
@@ -863,8 +886,15 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     s->why_generic = why;
     if (e == hipSuccess && s->octree) e = up(s->onodes, hon);
     if (e == hipSuccess && s->octree) e = up(s->oblocks, hob);
-    if (e == hipSuccess) e = s->ctrl.ensure(1);
-    for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&s->ev[k]);
+    for (int k = 0; k < 2 && e == hipSuccess; k++) {
+        e = s->w[k].ctrl.ensure(1);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->istream[k], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreate(&s->w[k].ev[0]);
+        if (e == hipSuccess) e = hipEventCreate(&s->w[k].ev[1]);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->join_ev[k], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreate(&s->fork_ev);
+    if (e == hipSuccess) e = hipEventCreate(&s->end_ev);
     if (e != hipSuccess) {
         std::string msg = std::string("scene upload: ") + hipGetErrorString(e);
         rtmi_scene_destroy(s);
@@ -891,11 +921,14 @@ int rtmi_scene_destroy(rtmi_scene_t* s) {
     (void)hipSetDevice(s->device);
     s->nodes.release(); s->refs.release(); s->tplane.release(); s->tedge.release(); s->mats.release();
     s->onodes.release(); s->oblocks.release();
-    for (int k = 0; k < 2; k++) { s->qo[k].release(); s->qd[k].release(); s->qpath[k].release(); }
-    s->scol.release(); s->tile.release(); s->hit_tf.release(); s->redo.release(); s->hit_t.release(); s->mstack.release();
-    s->ctrl.release(); s->qbytes.release();
-    for (int k = 0; k < 4; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
-    for (hipEvent_t e : s->pass_ev) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; k++) {
+        s->w[k].release();
+        if (s->istream[k]) (void)hipStreamDestroy(s->istream[k]);
+        if (s->join_ev[k]) (void)hipEventDestroy(s->join_ev[k]);
+    }
+    if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
+    if (s->end_ev) (void)hipEventDestroy(s->end_ev);
+    s->tile.release(); s->qbytes.release();
     delete s;
     return RTMI_OK;
 }
@@ -906,55 +939,60 @@ int rtmi_scene_set_options(rtmi_scene_t* s, uint32_t options) {
     return RTMI_OK;
 }
 
-static int ensure_workspace(rtmi_scene* s, size_t cap, uint32_t maxdepth) {
-    if (cap <= s->cap && maxdepth <= s->cap_depth) return RTMI_OK;
-    cap = std::max(cap, s->cap);
-    maxdepth = std::max(maxdepth, s->cap_depth);
+static int ensure_workspace(Work& w, size_t cap, uint32_t maxdepth) {
+    if (cap <= w.cap && maxdepth <= w.cap_depth) return RTMI_OK;
+    cap = std::max(cap, w.cap);
+    maxdepth = std::max(maxdepth, w.cap_depth);
     for (int k = 0; k < 2; k++) {
-        HIPCHK(s->qo[k].ensure(cap));
-        HIPCHK(s->qd[k].ensure(cap));
-        HIPCHK(s->qpath[k].ensure(cap));
+        HIPCHK(w.qo[k].ensure(cap));
+        HIPCHK(w.qd[k].ensure(cap));
+        HIPCHK(w.qpath[k].ensure(cap));
     }
-    HIPCHK(s->scol.ensure(cap));
-    HIPCHK(s->hit_tf.ensure(cap));
-    HIPCHK(s->redo.ensure(cap));
-    HIPCHK(s->hit_t.ensure(cap));
-    HIPCHK(s->mstack.ensure(cap * (size_t)maxdepth));
-    s->cap = cap;
-    s->cap_depth = maxdepth;
+    HIPCHK(w.scol.ensure(cap));
+    HIPCHK(w.hit_tf.ensure(cap));
+    HIPCHK(w.redo.ensure(cap));
+    HIPCHK(w.hit_t.ensure(cap));
+    HIPCHK(w.mstack.ensure(cap * (size_t)maxdepth));
+    while (w.pass_ev.size() < 2 * (size_t)std::max<uint32_t>(maxdepth, 1u)) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        w.pass_ev.push_back(e);
+    }
+    w.cap = cap;
+    w.cap_depth = maxdepth;
     return RTMI_OK;
 }
 
 extern "C++" {
 template <bool COUNT>
-static void launch_trace(rtmi_scene* s, hipStream_t st, const float4* qo, const float4* qd, int pass) {
+static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* qo, const float4* qd, int pass) {
     if (s->root_is_leaf && !(s->options & RTMI_OPT_GENERIC)) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_linear<COUNT>), dim3((unsigned)(s->num_cu * 8)), dim3(256), 0, st, s->d, qo, qd,
-                           s->ctrl.p, pass, s->hit_tf.p, s->hit_t.p);
+                           w.ctrl.p, pass, w.hit_tf.p, w.hit_t.p);
         return;
     }
     if (s->octree && !(s->options & RTMI_OPT_GENERIC)) {
         const int per_cu = (int)env_size("RTMI_OCT_WAVES_PER_CU", (size_t)s->oct_blocks_per_cu);
         dim3 grid((unsigned)(s->num_cu * per_cu)), block(64);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT>), grid, block, s->oct_lds, st, s->d, qo, qd, s->ctrl.p, pass,
-                           s->hit_tf.p, s->hit_t.p, s->redo.p, (int)(pass == 0 ? env_size("RTMI_REFILL_MIN0", 64) : env_size("RTMI_REFILL_MIN", 8)),
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT>), grid, block, s->oct_lds, st, s->d, qo, qd, w.ctrl.p, pass,
+                           w.hit_tf.p, w.hit_t.p, w.redo.p, (int)(pass == 0 ? env_size("RTMI_REFILL_MIN0", 64) : env_size("RTMI_REFILL_MIN", 8)),
                            (int)env_size("RTMI_XCD_AWARE", 1) % 3);  // 1 = ranges by XCC_ID, 2 = by blockIdx % 8, 3 -> 0 = one range
         // exact re-trace of the (normally zero) rays whose leaf results contained a NaN hit time
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<false>), dim3(16), dim3((unsigned)s->trace_block), s->trace_lds, st, s->d, qo, qd,
-                           s->ctrl.p, pass, s->hit_tf.p, s->hit_t.p, (const uint32_t*)s->redo.p);
+                           w.ctrl.p, pass, w.hit_tf.p, w.hit_t.p, (const uint32_t*)w.redo.p);
         return;
     }
     // persistent grid: enough blocks to fill every CU at the occupancy LDS allows
     const int per_cu = s->trace_block == 256 ? 4 : 16;
     dim3 grid((unsigned)(s->num_cu * per_cu)), block((unsigned)s->trace_block);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<COUNT>), grid, block, s->trace_lds, st, s->d, qo, qd, s->ctrl.p, pass,
-                       s->hit_tf.p, s->hit_t.p, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<COUNT>), grid, block, s->trace_lds, st, s->d, qo, qd, w.ctrl.p, pass,
+                       w.hit_tf.p, w.hit_t.p, (const uint32_t*)nullptr);
 }
 }  // extern "C++"
 
-static int read_stats(rtmi_scene* s, hipStream_t st, rtmi_stats_t* stats, float kernel_ms, float trace_ms, uint32_t launches) {
+static int read_stats(Work& w, hipStream_t st, rtmi_stats_t* stats, float kernel_ms, float trace_ms, uint32_t launches) {
     DCtrl h;
-    HIPCHK(hipMemcpyAsync(&h, s->ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&h, w.ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (stats) {
         stats->rays += h.rays;
@@ -970,6 +1008,13 @@ int rtmi_render_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t seed
     const rtmi_tile_t tile{row0, nrows, nrows ? nrows : 1u, 0u};
     return rtmi_render_tile_device(s, vp, seed, &tile, out_device, hip_stream, stats);
 }
+
+// One sub-tile = every nsub-th stripe of the caller's tile, rendered on its own stream with its own workspace.
+struct SubTile {
+    DView dv;          // row mapping of the sub-tile's local rows (tile_pixel)
+    uint64_t npix = 0; // pixels of the sub-tile
+    uint32_t index = 0;
+};
 
 int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t seed, const rtmi_tile_t* tile,
                             void* out_device, void* hip_stream, rtmi_stats_t* stats) {
@@ -990,99 +1035,135 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     if (vp->maxdepth > RTMI_MAX_PASSES) return fail(RTMI_ERR_UNSUPPORTED, "maxdepth above 32");
     if ((uint64_t)vp->width * vp->height >= (1ull << 32)) return fail(RTMI_ERR_UNSUPPORTED, "more than 2^32 pixels");
     HIPCHK(hipSetDevice(s->device));
-    hipStream_t st = (hipStream_t)hip_stream;
+    hipStream_t ust = (hipStream_t)hip_stream;
     const uint32_t W = vp->width, spp = vp->samples_per_pixel, maxdepth = vp->maxdepth;
     const uint64_t npix = (uint64_t)nrows * W;
     float4* out = (float4*)out_device;
     if (maxdepth == 0) {  // project_ray returns black immediately (raytrace.rs:1261-1263); acc*(1/spp) of zeros
-        HIPCHK(hipMemsetAsync(out, 0, npix * sizeof(float4), st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemsetAsync(out, 0, npix * sizeof(float4), ust));
+        HIPCHK(hipStreamSynchronize(ust));
         return RTMI_OK;
     }
-    // batch = whole pixels with all their samples
-    const size_t want_paths = env_size("RTMI_BATCH_PATHS", (size_t)256 << 20);
-    uint64_t pix_per_batch = std::max<uint64_t>(1, want_paths / spp);
-    pix_per_batch = std::min<uint64_t>(pix_per_batch, npix);
-    if (pix_per_batch * spp >= (1ull << 31)) return fail(RTMI_ERR_UNSUPPORTED, "batch above 2^31 paths");
-    int rc = ensure_workspace(s, (size_t)(pix_per_batch * spp), maxdepth);
-    if (rc != RTMI_OK) return rc;
 
-    DView dv;
-    dv.orig = mk(vp->orig[0], vp->orig[1], vp->orig[2]);
-    dv.cam = mk(vp->cam[0], vp->cam[1], vp->cam[2]);
-    dv.vu = mk(vp->vu[0], vp->vu[1], vp->vu[2]);
-    dv.vv = mk(vp->vv[0], vp->vv[1], vp->vv[2]);
-    dv.width = W; dv.height = vp->height; dv.maxdepth = maxdepth; dv.spp = spp;
-    dv.row0 = row0; dv.stripe_rows = tile->stripe_rows; dv.stripe_step = tile->stripe_step; dv.pad = 0;
+    // ---- the caller's tile as stripes (a contiguous band is cut into <= 16-row stripes), split over the streams
+    uint32_t S = tile->stripe_rows, step = tile->stripe_step;
+    if ((uint64_t)S >= nrows) {  // one stripe = contiguous band
+        S = std::min<uint32_t>(16u, std::max<uint32_t>(1u, (nrows + 1) / 2));
+        step = S;
+    }
+    const uint32_t nstripes = (nrows + S - 1) / S;
+    uint32_t nsub = (uint32_t)std::min<size_t>(env_size("RTMI_STREAMS", 2), 2);
+    if (nstripes < 2 || npix * spp < env_size("RTMI_SUBTILE_MIN_PATHS", 32768)) nsub = 1;
+    SubTile sub[2];
+    for (uint32_t t = 0; t < nsub; t++) {
+        DView& dv = sub[t].dv;
+        dv.orig = mk(vp->orig[0], vp->orig[1], vp->orig[2]);
+        dv.cam = mk(vp->cam[0], vp->cam[1], vp->cam[2]);
+        dv.vu = mk(vp->vu[0], vp->vu[1], vp->vu[2]);
+        dv.vv = mk(vp->vv[0], vp->vv[1], vp->vv[2]);
+        dv.width = W; dv.height = vp->height; dv.maxdepth = maxdepth; dv.spp = spp;
+        dv.row0 = row0 + t * step; dv.stripe_rows = S; dv.stripe_step = step * nsub; dv.pad = 0;
+        uint64_t rows = 0;
+        for (uint32_t k = t; k < nstripes; k += nsub) rows += std::min<uint32_t>(S, nrows - k * S);
+        sub[t].npix = rows * W;
+        sub[t].index = t;
+    }
+
+    // batch = whole pixels with all their samples
+    const size_t want_paths = env_size("RTMI_BATCH_PATHS", (size_t)256 << 20) / nsub;
+    uint64_t pix_per_batch = std::max<uint64_t>(1, want_paths / spp);
+    pix_per_batch = std::min<uint64_t>(pix_per_batch, std::max(sub[0].npix, sub[nsub - 1].npix));
+    if (pix_per_batch * spp >= (1ull << 31)) return fail(RTMI_ERR_UNSUPPORTED, "batch above 2^31 paths");
+    for (uint32_t t = 0; t < nsub; t++) {
+        int rc = ensure_workspace(s->w[t], (size_t)(std::min<uint64_t>(pix_per_batch, sub[t].npix) * spp), maxdepth);
+        if (rc != RTMI_OK) return rc;
+    }
 
     const bool counting = (s->options & RTMI_OPT_COUNTERS) != 0;
+    const bool verbose = getenv("RTMI_VERBOSE") != nullptr;
     const unsigned ew_blocks = (unsigned)(s->num_cu * 8);
-    float kernel_ms = 0.f, trace_ms = 0.f;
+    float trace_ms = 0.f;
     uint32_t launches = 0;
-    while (s->pass_ev.size() < 2 * (size_t)maxdepth) {
-        hipEvent_t e;
-        HIPCHK(hipEventCreate(&e));
-        s->pass_ev.push_back(e);
-    }
-    for (uint64_t p0 = 0; p0 < npix; p0 += pix_per_batch) {
-        const uint32_t np = (uint32_t)std::min<uint64_t>(pix_per_batch, npix - p0);
-        const uint32_t npaths = np * spp;
-        const uint32_t pix0 = (uint32_t)p0;  // local pixel index inside the tile
-        HIPCHK(hipMemsetAsync(s->ctrl.p, 0, sizeof(DCtrl), st));
-        HIPCHK(hipEventRecord(s->ev[0], st));
-        hipLaunchKernelGGL(k_gen, dim3(ew_blocks), dim3(256), 0, st, dv, seed, pix0, npaths, s->qo[0].p, s->qd[0].p, s->qpath[0].p, s->ctrl.p);
-        float tms = 0.f;
-        for (uint32_t pass = 0; pass < maxdepth; pass++) {
-            const int a = pass & 1, b = a ^ 1;
-            HIPCHK(hipEventRecord(s->pass_ev[2 * pass], st));
-            if (counting) launch_trace<true>(s, st, s->qo[a].p, s->qd[a].p, (int)pass);
-            else launch_trace<false>(s, st, s->qo[a].p, s->qd[a].p, (int)pass);
-            HIPCHK(hipEventRecord(s->pass_ev[2 * pass + 1], st));
-            if (counting && getenv("RTMI_VERBOSE")) {
-                DCtrl hc2;
-                HIPCHK(hipMemcpyAsync(&hc2, s->ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
-                static unsigned long long prev[5 + 8];
-                if (pass == 0) memset(prev, 0, sizeof(prev));
-                unsigned long long cur[13];
-                for (int k = 0; k < 5; k++) cur[k] = hc2.counters[k];
-                for (int k = 0; k < 8; k++) cur[5 + k] = hc2.dbg[k];
-                const double n = hc2.count[pass] ? (double)hc2.count[pass] : 1.0;
-                fprintf(stderr, "[rtmi]   pass %u per ray: box %.1f tri %.1f full %.2f nodes %.1f leaves %.1f | S-steps %.1f (util %.2f) L-steps %.1f (util %.2f)\n",
-                        pass, (cur[0] - prev[0]) / n, (cur[1] - prev[1]) / n, (cur[2] - prev[2]) / n, (cur[3] - prev[3]) / n, (cur[4] - prev[4]) / n,
-                        (cur[6] - prev[6]) / n, (double)(cur[6] - prev[6]) / (64.0 * (cur[5] - prev[5] ? cur[5] - prev[5] : 1)),
-                        (cur[8] - prev[8]) / n, (double)(cur[8] - prev[8]) / (64.0 * (cur[7] - prev[7] ? cur[7] - prev[7] : 1)));
-                memcpy(prev, cur, sizeof(prev));
+    // internal streams start after whatever the caller queued on its stream
+    HIPCHK(hipEventRecord(s->fork_ev, ust));
+    for (uint32_t t = 0; t < nsub; t++) HIPCHK(hipStreamWaitEvent(s->istream[t], s->fork_ev, 0));
+
+    const uint64_t max_npix = std::max(sub[0].npix, sub[nsub - 1].npix);
+    for (uint64_t p0 = 0; p0 < max_npix; p0 += pix_per_batch) {
+        // enqueue this batch of every sub-tile (no host dependency inside a batch: queue sizes live on the device)
+        for (uint32_t t = 0; t < nsub; t++) {
+            if (p0 >= sub[t].npix) continue;
+            Work& w = s->w[t];
+            hipStream_t st = s->istream[t];
+            const DView& dv = sub[t].dv;
+            const uint32_t np = (uint32_t)std::min<uint64_t>(pix_per_batch, sub[t].npix - p0);
+            const uint32_t npaths = np * spp;
+            const uint32_t pix0 = (uint32_t)p0;  // local pixel index inside the sub-tile
+            HIPCHK(hipMemsetAsync(w.ctrl.p, 0, sizeof(DCtrl), st));
+            HIPCHK(hipEventRecord(w.ev[0], st));
+            hipLaunchKernelGGL(k_gen, dim3(ew_blocks), dim3(256), 0, st, dv, seed, pix0, npaths, w.qo[0].p, w.qd[0].p, w.qpath[0].p, w.ctrl.p);
+            for (uint32_t pass = 0; pass < maxdepth; pass++) {
+                const int a = pass & 1, b = a ^ 1;
+                HIPCHK(hipEventRecord(w.pass_ev[2 * pass], st));
+                if (counting) launch_trace<true>(s, w, st, w.qo[a].p, w.qd[a].p, (int)pass);
+                else launch_trace<false>(s, w, st, w.qo[a].p, w.qd[a].p, (int)pass);
+                HIPCHK(hipEventRecord(w.pass_ev[2 * pass + 1], st));
+                if (counting && verbose) {
+                    DCtrl hc2;
+                    HIPCHK(hipMemcpyAsync(&hc2, w.ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    static unsigned long long prev[2][5 + 8];
+                    if (pass == 0) memset(prev[t], 0, sizeof(prev[t]));
+                    unsigned long long cur[13];
+                    for (int k = 0; k < 5; k++) cur[k] = hc2.counters[k];
+                    for (int k = 0; k < 8; k++) cur[5 + k] = hc2.dbg[k];
+                    const double n = hc2.count[pass] ? (double)hc2.count[pass] : 1.0;
+                    fprintf(stderr, "[rtmi]   stream %u pass %u per ray: box %.1f tri %.1f full %.2f nodes %.1f leaves %.1f | S-steps %.1f (util %.2f) L-steps %.1f (util %.2f)\n",
+                            t, pass, (cur[0] - prev[t][0]) / n, (cur[1] - prev[t][1]) / n, (cur[2] - prev[t][2]) / n, (cur[3] - prev[t][3]) / n, (cur[4] - prev[t][4]) / n,
+                            (cur[6] - prev[t][6]) / n, (double)(cur[6] - prev[t][6]) / (64.0 * (cur[5] - prev[t][5] ? cur[5] - prev[t][5] : 1)),
+                            (cur[8] - prev[t][8]) / n, (double)(cur[8] - prev[t][8]) / (64.0 * (cur[7] - prev[t][7] ? cur[7] - prev[t][7] : 1)));
+                    memcpy(prev[t], cur, sizeof(prev[t]));
+                }
+                hipLaunchKernelGGL(k_shade, dim3(ew_blocks), dim3(256), 0, st, s->d, dv, seed, pix0, npaths, (int)pass,
+                                   w.qo[a].p, w.qd[a].p, w.qpath[a].p, w.hit_tf.p, w.hit_t.p, w.qo[b].p, w.qd[b].p,
+                                   w.qpath[b].p, w.mstack.p, w.scol.p, w.ctrl.p);
+                launches++;
             }
-            hipLaunchKernelGGL(k_shade, dim3(ew_blocks), dim3(256), 0, st, s->d, dv, seed, pix0, npaths, (int)pass,
-                               s->qo[a].p, s->qd[a].p, s->qpath[a].p, s->hit_tf.p, s->hit_t.p, s->qo[b].p, s->qd[b].p,
-                               s->qpath[b].p, s->mstack.p, s->scol.p, s->ctrl.p);
-            launches++;
+            hipLaunchKernelGGL(k_accum, dim3(ew_blocks), dim3(256), 0, st, np, spp, w.scol.p, out, pix0, W, S, nsub, t);
+            HIPCHK(hipEventRecord(w.ev[1], st));
+            HIPCHK(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_accum, dim3(ew_blocks), dim3(256), 0, st, np, spp, s->scol.p, out + p0);
-        HIPCHK(hipEventRecord(s->ev[1], st));
-        HIPCHK(hipGetLastError());
-        rtmi_stats_t bs; memset(&bs, 0, sizeof(bs));
-        rc = read_stats(s, st, &bs, 0.f, 0.f, 0);
-        if (rc != RTMI_OK) return rc;
-        float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
-        DCtrl hc;
-        const bool verbose = getenv("RTMI_VERBOSE") != nullptr;
-        if (verbose) HIPCHK(hipMemcpy(&hc, s->ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost));
-        for (uint32_t pass = 0; pass < maxdepth; pass++) {
-            float pm = 0.f;
-            HIPCHK(hipEventElapsedTime(&pm, s->pass_ev[2 * pass], s->pass_ev[2 * pass + 1]));
-            tms += pm;
-            if (verbose) fprintf(stderr, "[rtmi] batch@%llu pass %u: %u rays, trace %.3f ms, %.1f Mrays/s\n", (unsigned long long)p0, pass, hc.count[pass], pm, hc.count[pass] / (pm * 1e3));
-        }
-        kernel_ms += ms; trace_ms += tms;
-        if (stats) {
-            stats->rays += bs.rays; stats->box_tests += bs.box_tests; stats->tri_tests += bs.tri_tests;
-            stats->full_tests += bs.full_tests; stats->nodes += bs.nodes; stats->leaves += bs.leaves;
+        // collect: counters and per-launch trace times of every sub-tile's batch
+        for (uint32_t t = 0; t < nsub; t++) {
+            if (p0 >= sub[t].npix) continue;
+            Work& w = s->w[t];
+            rtmi_stats_t bs; memset(&bs, 0, sizeof(bs));
+            int rc = read_stats(w, s->istream[t], &bs, 0.f, 0.f, 0);
+            if (rc != RTMI_OK) return rc;
+            DCtrl hc;
+            if (verbose) HIPCHK(hipMemcpy(&hc, w.ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost));
+            for (uint32_t pass = 0; pass < maxdepth; pass++) {
+                float pm = 0.f;
+                HIPCHK(hipEventElapsedTime(&pm, w.pass_ev[2 * pass], w.pass_ev[2 * pass + 1]));
+                trace_ms += pm;
+                if (verbose) fprintf(stderr, "[rtmi] stream %u batch@%llu pass %u: %u rays, trace %.3f ms, %.1f Mrays/s\n", t, (unsigned long long)p0, pass, hc.count[pass], pm, hc.count[pass] / (pm * 1e3));
+            }
+            if (stats) {
+                stats->rays += bs.rays; stats->box_tests += bs.box_tests; stats->tri_tests += bs.tri_tests;
+                stats->full_tests += bs.full_tests; stats->nodes += bs.nodes; stats->leaves += bs.leaves;
+            }
         }
     }
-    if (stats) { stats->kernel_ms = kernel_ms; stats->trace_ms = trace_ms; stats->trace_launches = launches; }
+    // the caller's stream continues after both internal streams
+    for (uint32_t t = 0; t < nsub; t++) {
+        HIPCHK(hipEventRecord(s->join_ev[t], s->istream[t]));
+        HIPCHK(hipStreamWaitEvent(ust, s->join_ev[t], 0));
+    }
+    HIPCHK(hipEventRecord(s->end_ev, ust));
+    HIPCHK(hipEventSynchronize(s->end_ev));
+    float kernel_ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&kernel_ms, s->fork_ev, s->end_ev));
+    if (stats) { stats->kernel_ms = kernel_ms; stats->trace_ms = trace_ms; stats->trace_launches = launches; stats->streams = nsub; }
     return RTMI_OK;
 }
 
@@ -1107,36 +1188,42 @@ int rtmi_trace(rtmi_scene_t* s, uint64_t n, const float* orig4, const float* dir
     if (!orig4 || !dir4 || !tri || !t || !face) return fail(RTMI_ERR_INVALID, "NULL argument");
     if (n >= (1ull << 31)) return fail(RTMI_ERR_UNSUPPORTED, "more than 2^31 rays per call");
     HIPCHK(hipSetDevice(s->device));
-    int rc = ensure_workspace(s, (size_t)n, 1);
+    Work& w = s->w[0];
+    int rc = ensure_workspace(w, (size_t)n, 1);
     if (rc != RTMI_OK) return rc;
-    hipStream_t st = nullptr;
-    HIPCHK(hipMemcpyAsync(s->qo[0].p, orig4, n * 16, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(s->qd[0].p, dir4, n * 16, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(s->ctrl.p, 0, sizeof(DCtrl), st));
-    hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, s->ctrl.p, (uint32_t)n);
-    HIPCHK(hipEventRecord(s->ev[0], st));
-    if (s->options & RTMI_OPT_COUNTERS) launch_trace<true>(s, st, s->qo[0].p, s->qd[0].p, 0);
-    else launch_trace<false>(s, st, s->qo[0].p, s->qd[0].p, 0);
-    HIPCHK(hipEventRecord(s->ev[1], st));
+    hipStream_t st = s->istream[0];
+    HIPCHK(hipMemcpyAsync(w.qo[0].p, orig4, n * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(w.qd[0].p, dir4, n * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(w.ctrl.p, 0, sizeof(DCtrl), st));
+    hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, w.ctrl.p, (uint32_t)n);
+    HIPCHK(hipEventRecord(w.ev[0], st));
+    if (s->options & RTMI_OPT_COUNTERS) launch_trace<true>(s, w, st, w.qo[0].p, w.qd[0].p, 0);
+    else launch_trace<false>(s, w, st, w.qo[0].p, w.qd[0].p, 0);
+    HIPCHK(hipEventRecord(w.ev[1], st));
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> tf(n);
-    HIPCHK(hipMemcpyAsync(tf.data(), s->hit_tf.p, n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(t, s->hit_t.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(tf.data(), w.hit_tf.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(t, w.hit_t.p, n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (uint64_t i = 0; i < n; i++) { tri[i] = tf[i] & 0x3FFFFFFFu; face[i] = tf[i] >> 30; }
     // face encoding of the ABI: 0 front 1 back 2 edge-front 3 edge-back (bit0 = back, bit1 = edge)
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
-    return read_stats(s, st, stats, ms, ms, 1);
+    HIPCHK(hipEventElapsedTime(&ms, w.ev[0], w.ev[1]));
+    rc = read_stats(w, st, stats, ms, ms, 1);
+    if (stats) stats->streams = 1;
+    return rc;
 }
 
 // Development aid (not in rtmi.h): step statistics of the last counting render/trace.
 int rtmi_debug_counters(rtmi_scene_t* s, unsigned long long* out16) {
     if (!s || !out16) return fail(RTMI_ERR_INVALID, "NULL argument");
     HIPCHK(hipSetDevice(s->device));
-    DCtrl h;
-    HIPCHK(hipMemcpy(&h, s->ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost));
-    memcpy(out16, h.dbg, sizeof(h.dbg));
+    memset(out16, 0, 16 * sizeof(unsigned long long));
+    for (int k = 0; k < 2; k++) {
+        DCtrl h;
+        HIPCHK(hipMemcpy(&h, s->w[k].ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost));
+        for (int j = 0; j < 16; j++) out16[j] += h.dbg[j];
+    }
     return RTMI_OK;
 }
 

@@ -415,3 +415,35 @@ def test_odd_sizes_and_many_samples(circles_pair):
         ctx = R.HipRayCaster(seed=6).walk_rays(vp, sp, img, 1, False)
         assert_bits_equal(ref, img, f"image {w}x{h}x{spp}")
         assert ctx.total_rays == cn["rays"]
+
+
+def test_two_stream_subtiles_small_and_ragged(canonical_pair, monkeypatch):
+    """The library splits a tile into two interleaved sub-tiles on two internal streams.  Force that on small,
+    odd-sized images (partial last stripe, contiguous bands, striped tiles) and compare with the one-stream result."""
+    import torch
+    from rust_raytrace_amd import dist as rd
+    so, sp = canonical_pair
+    orc, R = _orc(), _R()
+    for (w, h, spp) in ((24, 37, 2), (9, 50, 3), (16, 3, 4)):
+        vo = orc.canonical_viewport(w, h)
+        vp = R.canonical_viewport(w, h, 5, spp)
+        ref, cn = so.render(w, h, vo, 5, spp, seed=4, threads=8)
+        monkeypatch.setenv("RTMI_SUBTILE_MIN_PATHS", "1")
+        img = np.zeros((h, w, 4), np.float32)
+        ctx = R.HipRayCaster(seed=4).walk_rays(vp, sp, img, 1, False)
+        assert ctx.stats["streams"] == (2 if h >= 2 else 1)
+        assert_bits_equal(ref, img, f"two streams {w}x{h}")
+        assert ctx.total_rays == cn["rays"]
+        # a striped tile (rank 1 of 3, 4-row stripes) with both streams
+        tile = rd.rank_tile(1, 3, h, 4)
+        if tile[1]:
+            buf = torch.zeros((tile[1], w, 4), dtype=torch.float32, device="cuda:0")
+            R.HipRayCaster(seed=4).walk_tile_device(vp, sp, tile, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert_bits_equal(ref[rd.tile_rows(tile, h)], buf.cpu().numpy(), f"striped two streams {w}x{h}")
+        monkeypatch.setenv("RTMI_STREAMS", "1")
+        one = np.zeros((h, w, 4), np.float32)
+        ctx1 = R.HipRayCaster(seed=4).walk_rays(vp, sp, one, 1, False)
+        assert ctx1.stats["streams"] == 1
+        assert_bits_equal(ref, one, f"one stream {w}x{h}")
+        monkeypatch.delenv("RTMI_STREAMS")

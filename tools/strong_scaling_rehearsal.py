@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Rehearsal on ONE GPU of the per-rank render time of config 3 tiled over N ranks (no gather):
+time of rank r's stripes, for every r, so that max_r predicts the N-GPU frame time."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from rust_raytrace_amd import raytrace as R, dist as rd
+W = H = 2048
+spp = 64
+STRIPE = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+scene = R.canonical_scene(os.path.join(ROOT, "tests", "golden", "teapot_tri.obj"))
+vp = R.canonical_viewport(W, H, 5, spp)
+c = R.HipRayCaster(seed=1)
+c.upload(scene)
+st = torch.cuda.current_stream().cuda_stream
+base = None
+for world in (1, 8):
+    times, rays = [], 0
+    for r in range(world):
+        tile = rd.rank_tile(r, world, H, STRIPE)
+        buf = torch.zeros((tile[1], W, 4), dtype=torch.float32, device="cuda:0")
+        c.walk_tile_device(vp, scene, tile, buf.data_ptr(), st)  # warm-up (allocations)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ctx = c.walk_tile_device(vp, scene, tile, buf.data_ptr(), st)
+        torch.cuda.synchronize(); times.append(time.perf_counter() - t0); rays += ctx.total_rays
+    if base is None:
+        base = max(times)
+    print([round(t*1e3,1) for t in times]); print(f"N={world}: per-rank render time max {max(times)*1e3:.1f} ms min {min(times)*1e3:.1f} ms -> predicted {rays / max(times) / 1e6:.0f} Mrays/s, "
+          f"efficiency {base / (world * max(times)):.2f} (before the gather)")
