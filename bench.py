@@ -156,12 +156,13 @@ def main():
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(avg_launch_ms, 3),
                         "bytes_per_ray": round(alg_bytes / max(st["rays"], 1), 1),
-                        "concurrent_launches": nstreams,
-                        "achieved_chip": round(achieved * nstreams, 1), "frac_chip": round(achieved * nstreams / HBM_PEAK_GBS, 4),
-                        "trace_share_of_kernel_time": round(trace_ms / max(kernel_ms * nstreams, 1e-9), 3),
-                        "note": "achieved = algorithmic bytes of ONE launch / its HIP-event duration; the library runs "
-                                f"{nstreams} such launches concurrently (two sub-tiles on two streams), so the chip-level rate is "
-                                "achieved_chip.  The records are served from L2/Infinity Cache (scene ~19 MB): VALU/latency-bound, see DESIGN.md"}
+                        "streams": nstreams,
+                        "achieved_chip": round(alg_bytes / (kernel_ms / args.steps * 1e-3) / 1e9, 1),
+                        "frac_chip": round(alg_bytes / (kernel_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "achieved = algorithmic bytes of ONE k_trace_oct launch / its HIP-event duration (agrees with the "
+                                "rocprofv3 average in profiles/); the library runs two sub-tiles on two streams whose launches "
+                                "partly overlap, so achieved_chip = algorithmic bytes of a frame / device time of the frame.  The "
+                                "records are served from L2/Infinity Cache (scene ~19 MB): VALU/latency-bound, see DESIGN.md"}
         if world == 1 and not args.no_cpu_baseline and args.scene == "canonical":
             from oracle import orc
             cw, ch, cspp = (int(x) for x in args.cpu_sample.split("x"))

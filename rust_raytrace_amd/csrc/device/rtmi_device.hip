@@ -965,10 +965,13 @@ static int ensure_workspace(Work& w, size_t cap, uint32_t maxdepth) {
 
 extern "C++" {
 template <bool COUNT>
-static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* qo, const float4* qd, int pass) {
+static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* qo, const float4* qd, int pass, hipEvent_t stop) {
+    // `stop` is recorded right after the closest-hit kernel proper (before the NaN-redo launch), so that the
+    // event pair of the caller times exactly the kernel rocprofv3 lists as k_trace_oct / k_trace_linear / k_trace
     if (s->root_is_leaf && !(s->options & RTMI_OPT_GENERIC)) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_linear<COUNT>), dim3((unsigned)(s->num_cu * 8)), dim3(256), 0, st, s->d, qo, qd,
                            w.ctrl.p, pass, w.hit_tf.p, w.hit_t.p);
+        (void)hipEventRecord(stop, st);
         return;
     }
     if (s->octree && !(s->options & RTMI_OPT_GENERIC)) {
@@ -977,8 +980,9 @@ static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* q
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT>), grid, block, s->oct_lds, st, s->d, qo, qd, w.ctrl.p, pass,
                            w.hit_tf.p, w.hit_t.p, w.redo.p, (int)(pass == 0 ? env_size("RTMI_REFILL_MIN0", 64) : env_size("RTMI_REFILL_MIN", 8)),
                            (int)env_size("RTMI_XCD_AWARE", 1) % 3);  // 1 = ranges by XCC_ID, 2 = by blockIdx % 8, 3 -> 0 = one range
+        (void)hipEventRecord(stop, st);
         // exact re-trace of the (normally zero) rays whose leaf results contained a NaN hit time
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<false>), dim3(16), dim3((unsigned)s->trace_block), s->trace_lds, st, s->d, qo, qd,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<false>), dim3(4), dim3((unsigned)s->trace_block), s->trace_lds, st, s->d, qo, qd,
                            w.ctrl.p, pass, w.hit_tf.p, w.hit_t.p, (const uint32_t*)w.redo.p);
         return;
     }
@@ -987,6 +991,7 @@ static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* q
     dim3 grid((unsigned)(s->num_cu * per_cu)), block((unsigned)s->trace_block);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<COUNT>), grid, block, s->trace_lds, st, s->d, qo, qd, w.ctrl.p, pass,
                        w.hit_tf.p, w.hit_t.p, (const uint32_t*)nullptr);
+    (void)hipEventRecord(stop, st);
 }
 }  // extern "C++"
 
@@ -1105,9 +1110,8 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
             for (uint32_t pass = 0; pass < maxdepth; pass++) {
                 const int a = pass & 1, b = a ^ 1;
                 HIPCHK(hipEventRecord(w.pass_ev[2 * pass], st));
-                if (counting) launch_trace<true>(s, w, st, w.qo[a].p, w.qd[a].p, (int)pass);
-                else launch_trace<false>(s, w, st, w.qo[a].p, w.qd[a].p, (int)pass);
-                HIPCHK(hipEventRecord(w.pass_ev[2 * pass + 1], st));
+                if (counting) launch_trace<true>(s, w, st, w.qo[a].p, w.qd[a].p, (int)pass, w.pass_ev[2 * pass + 1]);
+                else launch_trace<false>(s, w, st, w.qo[a].p, w.qd[a].p, (int)pass, w.pass_ev[2 * pass + 1]);
                 if (counting && verbose) {
                     DCtrl hc2;
                     HIPCHK(hipMemcpyAsync(&hc2, w.ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost, st));
@@ -1197,9 +1201,8 @@ int rtmi_trace(rtmi_scene_t* s, uint64_t n, const float* orig4, const float* dir
     HIPCHK(hipMemsetAsync(w.ctrl.p, 0, sizeof(DCtrl), st));
     hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, w.ctrl.p, (uint32_t)n);
     HIPCHK(hipEventRecord(w.ev[0], st));
-    if (s->options & RTMI_OPT_COUNTERS) launch_trace<true>(s, w, st, w.qo[0].p, w.qd[0].p, 0);
-    else launch_trace<false>(s, w, st, w.qo[0].p, w.qd[0].p, 0);
-    HIPCHK(hipEventRecord(w.ev[1], st));
+    if (s->options & RTMI_OPT_COUNTERS) launch_trace<true>(s, w, st, w.qo[0].p, w.qd[0].p, 0, w.ev[1]);
+    else launch_trace<false>(s, w, st, w.qo[0].p, w.qd[0].p, 0, w.ev[1]);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> tf(n);
     HIPCHK(hipMemcpyAsync(tf.data(), w.hit_tf.p, n * 4, hipMemcpyDeviceToHost, st));
