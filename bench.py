@@ -69,12 +69,13 @@ def main():
 
     obj = os.path.join(ROOT, "tests", "golden", "teapot_tri.obj")
     t0 = time.time()
+    build_threads = max(1, len(os.sched_getaffinity(0)) // max(world, 1))  # ranks of one node share the host cores
     if args.scene == "grid":
-        scene = R.grid_scene(obj)
+        scene = R.grid_scene(obj, threads=build_threads)
     elif args.scene == "linear":
         scene = R.canonical_scene(os.path.join(ROOT, "tests", "golden", "teapot.obj"), accel="trivial")
     else:
-        scene = R.canonical_scene(obj)  # octree (10, 19)
+        scene = R.canonical_scene(obj, threads=build_threads)  # octree (10, 19)
     t_build = time.time() - t0
     W, H, spp = args.width, args.height, args.spp
     vp = R.canonical_viewport(W, H, args.maxdepth, spp)
