@@ -8,14 +8,14 @@ import torch
 from rust_raytrace_amd import raytrace as R, dist as rd
 W = H = 2048
 spp = 64
-STRIPE = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+STRIPE = int(sys.argv[1]) if len(sys.argv) > 1 else 16  # stripe height
 scene = R.canonical_scene(os.path.join(ROOT, "tests", "golden", "teapot_tri.obj"))
 vp = R.canonical_viewport(W, H, 5, spp)
 c = R.HipRayCaster(seed=1)
 c.upload(scene)
 st = torch.cuda.current_stream().cuda_stream
 base = None
-for world in (1, 8):
+for world in (1, 2, 4, 8):
     times, rays = [], 0
     for r in range(world):
         tile = rd.rank_tile(r, world, H, STRIPE)
