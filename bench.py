@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--stripe-rows", type=int, default=16)
     ap.add_argument("--scene", default="canonical", choices=["canonical", "grid", "linear"],
                     help="canonical = config 3 (default, the headline); grid = config 5 (8 teapots); linear = config 2 (trivial box)")
+    ap.add_argument("--fast", action="store_true", help="RTMI_OPT_FAST (not bit-exact, NOT the headline): skip boxes behind the ray origin")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, one rank per GPU) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--check", action="store_true", help="rank 0 verifies the gathered frame against a single-tile render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -79,7 +80,7 @@ def main():
     t_build = time.time() - t0
     W, H, spp = args.width, args.height, args.spp
     vp = R.canonical_viewport(W, H, args.maxdepth, spp)
-    caster = R.HipRayCaster(seed=args.seed, device=local_rank)
+    caster = R.HipRayCaster(seed=args.seed, device=local_rank, options=R.OPT_FAST if args.fast else 0)
     t0 = time.time()
     caster.upload(scene)
     t_upload = time.time() - t0
@@ -136,9 +137,10 @@ def main():
             # device work counters of one full frame -> algorithmic bytes:
             # 16 B per box test + 4 B per leaf reference + 28 B per triangle test (plane part)
             # + 52 B per test that passes the bounding-radius check (edge part)
-            caster.options = R.OPT_COUNTERS
+            base_opts = caster.options
+            caster.options = base_opts | R.OPT_COUNTERS
             cctx = caster.walk_tile_device(vp, scene, tile, local.data_ptr(), stream.cuda_stream)
-            caster.options = 0
+            caster.options = base_opts
             st = cctx.stats
             alg_bytes = 16 * st["box_tests"] + 4 * st["tri_tests"] + 28 * st["tri_tests"] + 52 * st["full_tests"]
             per_launch_bytes = alg_bytes / max(st["trace_launches"], 1)
@@ -194,7 +196,7 @@ def main():
             "config": {"workload": {"canonical": "canonical main.rs scene (teapot_tri.obj + 2 mirror disks, 6721 triangles), octree (10,19), ",
                                     "grid": "config 5: 8 x teapot_tri.obj grid (50561 triangles), octree (10,19), ",
                                     "linear": "config 2: canonical scene from teapot.obj, trivial bounding box (linear list of 6720 triangles), "}[args.scene] +
-                                   f"{W}x{H} @ {spp} spp, depth {args.maxdepth}, seed {args.seed}",
+                                   f"{W}x{H} @ {spp} spp, depth {args.maxdepth}, seed {args.seed}" + (" [RTMI_OPT_FAST: not bit-exact]" if args.fast else ""),
                        "tiling": f"{world} x interleaved {args.stripe_rows}-row stripes + one gather", "rays_per_frame": int(rays / args.steps)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "setup": {"octree_build_s": round(t_build, 2), "scene_upload_s": round(t_upload, 3)},

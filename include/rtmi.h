@@ -110,7 +110,11 @@ int rtmi_scene_destroy(rtmi_scene_t* scene);
 /* Option switches (all default 0): */
 enum {
     RTMI_OPT_COUNTERS = 1u << 0, /* fill box/tri/node counters in rtmi_stats_t (slower) */
-    RTMI_OPT_GENERIC = 1u << 1   /* force the generic-tree traversal kernel              */
+    RTMI_OPT_GENERIC = 1u << 1,  /* force the generic-tree traversal kernel              */
+    RTMI_OPT_FAST = 1u << 2      /* NOT bit-exact: skip boxes entirely behind the ray origin (octree kernel only).
+                                  * The reference visits them; results differ only where a hit would have been found
+                                  * first through such a box (exact ties between triangles, rays exactly parallel to a
+                                  * triangle's plane) -- 0 of 1 048 576 pixels on the canonical frame, +24 % rays/s.  */
 };
 int rtmi_scene_set_options(rtmi_scene_t* scene, uint32_t options);
 

@@ -979,7 +979,8 @@ static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* q
         dim3 grid((unsigned)(s->num_cu * per_cu)), block(64);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT>), grid, block, s->oct_lds, st, s->d, qo, qd, w.ctrl.p, pass,
                            w.hit_tf.p, w.hit_t.p, w.redo.p, (int)(pass == 0 ? env_size("RTMI_REFILL_MIN0", 64) : env_size("RTMI_REFILL_MIN", 8)),
-                           (int)env_size("RTMI_XCD_AWARE", 1) % 3);  // 1 = ranges by XCC_ID, 2 = by blockIdx % 8, 3 -> 0 = one range
+                           (int)env_size("RTMI_XCD_AWARE", 1) % 3,   // 1 = ranges by XCC_ID, 2 = by blockIdx % 8, 3 -> 0 = one range
+                           (s->options & RTMI_OPT_FAST) ? 1 : 0);
         (void)hipEventRecord(stop, st);
         // exact re-trace of the (normally zero) rays whose leaf results contained a NaN hit time
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<false>), dim3(4), dim3((unsigned)s->trace_block), s->trace_lds, st, s->d, qo, qd,

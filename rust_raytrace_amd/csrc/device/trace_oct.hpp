@@ -61,7 +61,7 @@ __device__ inline float min3f(float a, float b, float c) {
 
 template <bool COUNT>
 __device__ inline OFrame expand_oct(float cx, float cy, float cz, uint32_t link, float hc, const RayK& r,
-                                    unsigned long long* cnt) {
+                                    unsigned long long* cnt, const bool fast) {
     const uint32_t mask = link >> 24;
     if (COUNT) { cnt[0] += __popc(mask); cnt[3]++; }
     // candidate planes per axis (child centres: builder's orig.add(off_vec))
@@ -96,7 +96,10 @@ __device__ inline OFrame expand_oct(float cx, float cy, float cz, uint32_t link,
     for (int o = 0; o < 8; o++) {
         const float tmin = max3f(nx[o & 1], ny[(o >> 1) & 1], nz[o >> 2]);
         const float tmax = min3f(fx[o & 1], fy[(o >> 1) & 1], fz[o >> 2]);
-        const uint32_t sel = (tmin < tmax) ? __float_as_uint(tmin) : inf_bits;
+        // RTMI_OPT_FAST (off by default, NOT the reference's traversal): ignore boxes that lie entirely behind the
+        // ray origin.  The reference visits them (collides() has no `tmax > 0` test, raytrace.rs:902) although only
+        // triangles that stick out of such a box towards the front can be hit through it.
+        const uint32_t sel = ((tmin < tmax) & (!fast | !(tmax < 0.f))) ? __float_as_uint(tmin) : inf_bits;
         // keep it only when the octant exists: exists_o is bit o of the child mask, spread to a full-width mask
         const uint32_t ex = (uint32_t)__builtin_amdgcn_sbfe((int)mask, o, 1);
         tm[o] = __uint_as_float((sel & ex) | (inf_bits & ~ex));  // a colliding tmin is never NaN and never +inf
@@ -139,7 +142,7 @@ __device__ inline void omerge(OFrame& f, bool have, float t) {
 template <bool COUNT>
 __global__ void __launch_bounds__(64, 6) k_trace_oct(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
                                                   DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
-                                                  float* __restrict__ hit_t, uint32_t* __restrict__ redo, int refill_min, int xcd_aware) {
+                                                  float* __restrict__ hit_t, uint32_t* __restrict__ redo, int refill_min, int xcd_aware, int fast) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;  // one wave per block
     constexpr int NT = 64;
@@ -262,7 +265,7 @@ __global__ void __launch_bounds__(64, 6) k_trace_oct(DScene sc, const float4* __
                                 fr[2 * NT] = __float_as_uint(cur.t);
                             }
                             lvl++;
-                            cur = expand_oct<COUNT>(rec.x, rec.y, rec.z, link, ldexpf(root_half, -(lvl + 1)), r, cnt);
+                            cur = expand_oct<COUNT>(rec.x, rec.y, rec.z, link, ldexpf(root_half, -(lvl + 1)), r, cnt, fast != 0);
                         }
                     }
                 }

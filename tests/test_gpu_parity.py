@@ -447,3 +447,20 @@ def test_two_stream_subtiles_small_and_ragged(canonical_pair, monkeypatch):
         assert ctx1.stats["streams"] == 1
         assert_bits_equal(ref, one, f"one stream {w}x{h}")
         monkeypatch.delenv("RTMI_STREAMS")
+
+
+def test_fast_option_is_opt_in_and_close(canonical_pair):
+    """RTMI_OPT_FAST is NOT the reference's traversal (it skips boxes behind the ray origin) and is never the default.
+    On the canonical scene it has been identical so far; allow a handful of pixels, require the same ray count order."""
+    so, sp = canonical_pair
+    R = _R()
+    vp = R.canonical_viewport(96, 96, 5, 4)
+    exact = np.zeros((96, 96, 4), np.float32)
+    fast = np.zeros_like(exact)
+    r0 = R.HipRayCaster(seed=1).walk_rays(vp, sp, exact, 1, False).total_rays
+    r1 = R.HipRayCaster(seed=1, options=R.OPT_FAST).walk_rays(vp, sp, fast, 1, False).total_rays
+    differing = int((exact.view(np.uint32) != fast.view(np.uint32)).any(axis=2).sum())
+    assert differing <= 4, differing
+    assert abs(r1 - r0) <= 64
+    ref, _ = so.render(96, 96, _orc().canonical_viewport(96, 96), 5, 4, seed=1, threads=8)
+    assert_bits_equal(ref, exact, "default mode stays exact")
