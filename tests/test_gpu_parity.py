@@ -464,3 +464,22 @@ def test_fast_option_is_opt_in_and_close(canonical_pair):
     assert abs(r1 - r0) <= 64
     ref, _ = so.render(96, 96, _orc().canonical_viewport(96, 96), 5, 4, seed=1, threads=8)
     assert_bits_equal(ref, exact, "default mode stays exact")
+
+
+def test_full_size_config3_sample_rows_vs_oracle(canonical_pair):
+    """BASELINE config 3 at its full size (2048 x 2048 @ 64 spp, depth 5, seed 1): six image rows, three of them through
+    the teapot, rendered by the HIP path and by the oracle — bit for bit, including the ray counts."""
+    import os
+    so, sp = canonical_pair
+    orc, R = _orc(), _R()
+    W = H = 2048
+    vo = orc.canonical_viewport(W, H)
+    vp = R.canonical_viewport(W, H, 5, 64)
+    c = R.HipRayCaster(seed=1)
+    threads = max(1, len(os.sched_getaffinity(0)))
+    for row in (0, 700, 1024, 1100, 1333, 2047):
+        ref, cn = so.render(W, H, vo, 5, 64, seed=1, row0=row, nrows=1, threads=threads)
+        got = np.zeros((1, W, 4), np.float32)
+        ctx = c.walk_rows(vp, sp, row, 1, got)
+        assert_bits_equal(ref, got, f"row {row}")
+        assert ctx.total_rays == cn["rays"], row
