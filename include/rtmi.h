@@ -24,9 +24,10 @@ extern "C" {
 enum {
     RTMI_OK = 0,
     RTMI_ERR_INVALID = 1,      /* bad argument / malformed scene            */
-    RTMI_ERR_NO_DEVICE = 2,    /* no HIP device / HIP runtime failure       */
+    RTMI_ERR_NO_DEVICE = 2,    /* no HIP device visible / bad device index  */
     RTMI_ERR_UNSUPPORTED = 3,  /* valid input outside what the kernels take */
-    RTMI_ERR_OOM = 4
+    RTMI_ERR_OOM = 4,          /* host or device allocation failed          */
+    RTMI_ERR_DEVICE = 5        /* any other HIP runtime / kernel failure    */
 };
 
 /* SurfaceKind (raytrace.rs:303-308) */
@@ -114,9 +115,27 @@ enum {
     RTMI_OPT_FAST = 1u << 2      /* NOT bit-exact: skip boxes entirely behind the ray origin (octree kernel only).
                                   * The reference visits them; results differ only where a hit would have been found
                                   * first through such a box (exact ties between triangles, rays exactly parallel to a
-                                  * triangle's plane) -- 0 of 1 048 576 pixels on the canonical frame, +24 % rays/s.  */
+                                  * triangle's plane).  Measured on config 3 (2048x2048 @ 64 spp): 17 of 4 194 304
+                                  * pixels differ from exact mode, 1.6x the rays/s.  Never the default.              */
 };
 int rtmi_scene_set_options(rtmi_scene_t* scene, uint32_t options);
+
+/* Launch tuning of one scene handle.  Defaults are taken ONCE, at rtmi_scene_create(), from the environment
+ * (RTMI_BATCH_PATHS, RTMI_STREAMS, RTMI_SUBTILE_MIN_PATHS, RTMI_OCT_WAVES_PER_CU, RTMI_REFILL_MIN0,
+ * RTMI_REFILL_MIN, RTMI_XCD_AWARE; RTMI_VERBOSE=1 prints per-pass timings to stderr) and can be read and changed
+ * here.  None of them changes a pixel: any batch size, stream count or stripe split gives the same image. */
+typedef struct rtmi_tuning {
+    uint64_t batch_paths;       /* paths (pixel samples) per batch of the wavefront pipeline; default 256 Mi  */
+    uint32_t streams;           /* 1 or 2 internal HIP streams (interleaved sub-tiles); default 2             */
+    uint32_t subtile_min_paths; /* tiles with fewer paths are not split over two streams; default 32768       */
+    uint32_t oct_waves_per_cu;  /* persistent waves per CU of the octree kernel; 0 = occupancy query          */
+    uint32_t refill_min0;       /* idle lanes before a wave refills, primary pass (64 = whole wave); default 64 */
+    uint32_t refill_min;        /* the same for bounce passes; default 8                                       */
+    uint32_t xcd_aware;         /* 1 = one ray-queue range per XCD (by XCC_ID), 2 = by block index, 0 = one queue */
+    uint32_t reserved;
+} rtmi_tuning_t;
+int rtmi_scene_get_tuning(rtmi_scene_t* scene, rtmi_tuning_t* out);
+int rtmi_scene_set_tuning(rtmi_scene_t* scene, const rtmi_tuning_t* in);
 
 /* Render image rows [row0, row0+nrows) of the viewport into `out`
  * (nrows*width*4 floats, row-major, RGB + a zero lane == `[Color]`,

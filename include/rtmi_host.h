@@ -73,6 +73,9 @@ int rth_caster_walk_tile_device(rth_scene_t* s, uint32_t w, uint32_t h, const fl
 int rth_caster_trace(rth_scene_t* s, uint64_t n, const float* orig4, const float* dir4, uint32_t* tri, float* t,
                      uint32_t* face, rtmi_stats_t* stats);
 int rth_caster_upload(rth_scene_t* s);
+/* Launch tuning for this scene's caster: fields that are 0 keep the library default, xcd_aware is passed as value + 1;
+ * NULL restores all defaults.  Never changes a pixel. */
+int rth_caster_set_tuning(rth_scene_t* s, const rtmi_tuning_t* tuning);
 int rth_caster_quantize_device(rth_scene_t* s, const void* rgba_device, uint64_t npixels, void* rgb_device, void* hip_stream); /* make the scene resident now (otherwise on first use) */
 
 /* write_png's quantisation on the host (raytrace.rs:1468-1473) */

@@ -58,7 +58,7 @@ struct DScene {
     const float4* mats;
     uint32_t nnodes, ntris, nmats, levels;
     // exact-octree form (trace_oct.hpp); null when the tree is not an exact octree
-    const float4* onodes;
+    const uint4* fnodes;
     const uint4* oblocks;
     float root_half;
     uint32_t olevels;
@@ -83,8 +83,6 @@ struct DCtrl {
     uint32_t count[RTMI_MAX_PASSES + 1];  // rays queued for pass k
     uint32_t head[RTMI_MAX_PASSES + 1];   // work-fetch cursor of pass k
     uint32_t xhead[RTMI_MAX_PASSES + 1][8];  // octree kernel: one cursor per XCD range of the queue
-    uint32_t redo[RTMI_MAX_PASSES + 1];   // rays of pass k the octree kernel hands to the generic kernel (NaN hit times)
-    uint32_t redo_head[RTMI_MAX_PASSES + 1];
     unsigned long long rays;              // sum of count[] (the "Rays" statistic)
     unsigned long long counters[5];       // box_tests tri_tests full_tests nodes leaves
     unsigned long long dbg[16];           // step statistics of the counting build (tools/step_stats.py)
@@ -304,23 +302,20 @@ __device__ inline bool traverse(const DScene& sc, const RayK& r, uint32_t* lds, 
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_trace(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
                                                DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
-                                               float* __restrict__ hit_t, const uint32_t* __restrict__ list) {
-    // list == nullptr: every ray of the pass.  list != nullptr: only the rays the octree kernel handed over
-    // (ctrl->redo[pass] of them); their work is not counted twice.
+                                               float* __restrict__ hit_t) {
     extern __shared__ uint32_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t count = list ? ctrl->redo[pass] : ctrl->count[pass];
-    uint32_t* head = list ? &ctrl->redo_head[pass] : &ctrl->head[pass];
-    if (!list && blockIdx.x == 0 && tid == 0) atomicAdd(&ctrl->rays, (unsigned long long)count);
+    const uint32_t count = ctrl->count[pass];
+    uint32_t* head = &ctrl->head[pass];
+    if (blockIdx.x == 0 && tid == 0) atomicAdd(&ctrl->rays, (unsigned long long)count);
     unsigned long long cnt[5] = {0, 0, 0, 0, 0};
     for (;;) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(head, 64u);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= count) break;
-        const uint32_t j = base + lane;
-        if (j < count) {
-            const uint32_t i = list ? list[j] : j;
+        const uint32_t i = base + lane;
+        if (i < count) {
             const RayK r = make_rayk(qo[i], qd[i]);
             float t = 0.f; uint32_t tf = 0;
             bool have = traverse<COUNT>(sc, r, lds, blockDim.x, tid, t, tf, cnt);
@@ -328,7 +323,7 @@ __global__ void __launch_bounds__(256) k_trace(DScene sc, const float4* __restri
             hit_t[i] = have ? t : 0.f;
         }
     }
-    if (COUNT && !list) {
+    if (COUNT) {
 #pragma unroll
         for (int k = 0; k < 5; k++)
             if (cnt[k]) atomicAdd(&ctrl->counters[k], cnt[k]);
@@ -638,13 +633,25 @@ __global__ void k_set_count(DCtrl* ctrl, uint32_t n) { ctrl->count[0] = n; }
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
+// HIP status -> ABI status: out of memory, "no device visible" and every other runtime failure are told apart
+static int hip_code(hipError_t e) {
+    if (e == hipErrorOutOfMemory) return RTMI_ERR_OOM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return RTMI_ERR_NO_DEVICE;
+    return RTMI_ERR_DEVICE;
+}
+
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess)                                                                          \
-            return fail(e_ == hipErrorOutOfMemory ? RTMI_ERR_OOM : RTMI_ERR_NO_DEVICE,                 \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                            \
+        if (e_ != hipSuccess) return fail(hip_code(e_), std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+// No C++ exception crosses the ABI: bodies that allocate host memory run inside this guard.
+#define RTMI_GUARD_BEGIN try {
+#define RTMI_GUARD_END                                                                                 \
+    } catch (const std::bad_alloc&) { return fail(RTMI_ERR_OOM, "host allocation failed");             \
+    } catch (const std::exception& ex_) { return fail(RTMI_ERR_INVALID, std::string("internal error: ") + ex_.what()); \
+    } catch (...) { return fail(RTMI_ERR_INVALID, "internal error"); }
 
 template <typename T>
 struct DevBuf {
@@ -670,7 +677,7 @@ struct Work {
     size_t cap = 0;
     uint32_t cap_depth = 0;
     DevBuf<float4> qo[2], qd[2], scol;
-    DevBuf<uint32_t> qpath[2], hit_tf, redo;
+    DevBuf<uint32_t> qpath[2], hit_tf;
     DevBuf<float> hit_t;
     DevBuf<uint16_t> mstack;
     DevBuf<DCtrl> ctrl;
@@ -678,7 +685,7 @@ struct Work {
     std::vector<hipEvent_t> pass_ev;  // start/stop of the trace kernel of every pass
     void release() {
         for (int k = 0; k < 2; k++) { qo[k].release(); qd[k].release(); qpath[k].release(); }
-        scol.release(); hit_tf.release(); redo.release(); hit_t.release(); mstack.release(); ctrl.release();
+        scol.release(); hit_tf.release(); hit_t.release(); mstack.release(); ctrl.release();
         for (int k = 0; k < 2; k++) if (ev[k]) { (void)hipEventDestroy(ev[k]); ev[k] = nullptr; }
         for (hipEvent_t e : pass_ev) (void)hipEventDestroy(e);
         pass_ev.clear();
@@ -692,8 +699,8 @@ struct rtmi_scene {
     DScene d{};
     DevBuf<DNode> nodes;
     DevBuf<uint32_t> refs;
-    DevBuf<float4> tplane, tedge, mats, onodes;
-    DevBuf<uint4> oblocks;
+    DevBuf<float4> tplane, tedge, mats;
+    DevBuf<uint4> fnodes, oblocks;
     bool root_is_leaf = false; // build_trivial_bounding_box: one list for every ray -> k_trace_linear
     bool octree = false;       // the tree passed the exact-octree check
     std::string why_generic;   // reason when it did not
@@ -709,6 +716,11 @@ struct rtmi_scene {
     int num_cu = 256;
     int trace_block = 256;
     size_t trace_lds = 0;
+    // tuning knobs, read from the environment ONCE at scene creation (getenv is not free and not thread-safe
+    // against setenv): waves per CU of the octree kernel, refill thresholds, XCD mode, streams, batch size
+    rtmi_tuning_t tune{};
+    bool verbose = false;
+    unsigned long long vprev[2][13] = {};  // verbose per-pass deltas (per handle: no shared statics)
 };
 
 static size_t env_size(const char* name, size_t dflt) {
@@ -716,7 +728,7 @@ static size_t env_size(const char* name, size_t dflt) {
     if (!s || !*s) return dflt;
     char* end = nullptr;
     unsigned long long v = strtoull(s, &end, 10);
-    return (end && *end == '\0' && v > 0) ? (size_t)v : dflt;
+    return (end && *end == '\0' && (v > 0 || dflt == 0)) ? (size_t)v : dflt;
 }
 
 extern "C" {
@@ -739,6 +751,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     if (ntris >= (1ull << 30)) return fail(RTMI_ERR_UNSUPPORTED, "more than 2^30 triangles");
     if (nboxes >= (1ull << 32) || nrefs >= (1ull << 32)) return fail(RTMI_ERR_UNSUPPORTED, "tree too large for 32-bit indices");
 
+    RTMI_GUARD_BEGIN
     // ---- validate the tree, compute inner depth (levels of the LDS stack)
     std::vector<uint32_t> depth(nboxes, 0xFFFFFFFFu);
     depth[0] = 0;
@@ -774,14 +787,17 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     }
     // ---- exact-octree form: every child must be the builder's octant of its parent, bit for bit
     //      (orig + (+-newlen2), newlen2 = len2 / 2, raytrace.rs:816-824), stored in octant order.
-    std::vector<float4> hon;
+    //      Inner boxes get a 64-B record (centre, child mask, 8 child links); leaves only their reference blocks.
+    std::vector<uint4> hfn;
     std::vector<uint4> hob;
     std::string why;
     {
         auto fb = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
-        bool ok = nboxes < (1ull << 24);
-        if (!ok) why = "more than 2^24 boxes";
-        std::vector<uint32_t> link(nboxes, 0);
+        bool ok = !boxes[0].is_leaf;  // a one-leaf tree is the linear list (k_trace_linear)
+        if (!ok) why = "the root box is a leaf";
+        // record index of every inner box (in box order, root = 0) / first reference block of every leaf
+        std::vector<uint32_t> slot(nboxes, 0);
+        uint64_t ninner = 0;
         const float root_len2 = boxes[0].len2;
         for (uint64_t i = 0; i < nboxes && ok; i++) {
             const rtmi_box_t& b = boxes[i];
@@ -790,8 +806,8 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
                 for (uint32_t k = 0; k < b.count; k++)
                     if (tri_refs[b.first + k] == 0) { ok = false; why = "a leaf lists the sentinel triangle 0"; }
                 if (!ok) break;
-                if (hob.size() >= (1ull << 24)) { ok = false; why = "more than 2^24 reference blocks"; break; }
-                link[i] = (uint32_t)hob.size();
+                if (hob.size() >= (1ull << 31)) { ok = false; why = "more than 2^31 reference blocks"; break; }
+                slot[i] = (uint32_t)hob.size() | 0x80000000u;
                 // blocks of 4 indices; the list ends at the first 0, or after a block whose 4th index carries
                 // bit 31 (a full last block: no extra all-zero block, triangle indices are < 2^30)
                 for (uint32_t k = 0; k < std::max<uint32_t>(b.count, 1u); k += 4) {
@@ -802,8 +818,16 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
                     hob.push_back(make_uint4(v[0], v[1], v[2], v[3]));
                 }
             } else {
+                slot[i] = (uint32_t)ninner++;
+            }
+        }
+        if (ok) {
+            hfn.assign(4 * ninner, make_uint4(0, 0, 0, 0));
+            for (uint64_t i = 0; i < nboxes && ok; i++) {
+                const rtmi_box_t& b = boxes[i];
+                if (b.is_leaf) continue;
                 const float h = b.len2 / 2.f;
-                uint32_t mask = 0;
+                uint32_t mask = 0, link[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 int prev = -1;
                 for (uint32_t k = 0; k < b.count && ok; k++) {
                     const rtmi_box_t& c = boxes[b.first + k];
@@ -817,17 +841,15 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
                     if (ok && oct <= prev) { ok = false; why = "children are not in octant order"; }
                     prev = oct;
                     mask |= 1u << oct;
+                    link[oct & 7] = slot[b.first + k];  // an inner child is never record 0 (that is the root)
                 }
-                link[i] = b.first | (mask << 24);
+                uint4* rec = &hfn[4 * (size_t)slot[i]];
+                rec[0] = make_uint4(fb(b.orig[0]), fb(b.orig[1]), fb(b.orig[2]), mask);
+                rec[1] = make_uint4(link[0], link[1], link[2], link[3]);
+                rec[2] = make_uint4(link[4], link[5], link[6], link[7]);
             }
         }
-        if (ok) {
-            hon.resize(nboxes);
-            for (uint64_t i = 0; i < nboxes; i++) {
-                float lf; memcpy(&lf, &link[i], 4);
-                hon[i] = make_float4(boxes[i].orig[0], boxes[i].orig[1], boxes[i].orig[2], lf);
-            }
-        } else { hon.clear(); hob.clear(); }
+        if (!ok) { hfn.clear(); hob.clear(); }
     }
 
     std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t> matmap;
@@ -862,9 +884,21 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     if (device < 0 || device >= ndev) return fail(RTMI_ERR_INVALID, "device index out of range");
     HIPCHK(hipSetDevice(device));
 
-    rtmi_scene* s = new (std::nothrow) rtmi_scene();
-    if (!s) return fail(RTMI_ERR_OOM, "host allocation failed");
+    std::vector<uint32_t> hrefs(tri_refs, tri_refs + nrefs);
+    struct Owner {  // destroys a half-built scene on any early exit, exceptions included
+        rtmi_scene* s;
+        ~Owner() { if (s) rtmi_scene_destroy(s); }
+    } own{new rtmi_scene()};
+    rtmi_scene* s = own.s;
     s->device = device;
+    s->tune.batch_paths = env_size("RTMI_BATCH_PATHS", (size_t)256 << 20);
+    s->tune.streams = (uint32_t)std::min<size_t>(env_size("RTMI_STREAMS", 2), 2);
+    s->tune.subtile_min_paths = (uint32_t)std::min<size_t>(env_size("RTMI_SUBTILE_MIN_PATHS", 32768), 0xFFFFFFFFu);
+    s->tune.oct_waves_per_cu = (uint32_t)std::min<size_t>(env_size("RTMI_OCT_WAVES_PER_CU", 0), 32);
+    s->tune.refill_min0 = (uint32_t)std::min<size_t>(env_size("RTMI_REFILL_MIN0", 64), 64);
+    s->tune.refill_min = (uint32_t)std::min<size_t>(env_size("RTMI_REFILL_MIN", 8), 64);
+    s->tune.xcd_aware = (uint32_t)(env_size("RTMI_XCD_AWARE", 1) % 3);
+    s->verbose = getenv("RTMI_VERBOSE") != nullptr;
     s->trace_block = block;
     s->trace_lds = (size_t)levels * 16 * block;
     hipDeviceProp_t prop;
@@ -875,16 +909,15 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
         if (host.empty()) return hipSuccess;
         return hipMemcpy(buf.p, host.data(), host.size() * sizeof(host[0]), hipMemcpyHostToDevice);
     };
-    std::vector<uint32_t> hrefs(tri_refs, tri_refs + nrefs);
     hipError_t e = up(s->nodes, hn);
     if (e == hipSuccess) e = up(s->refs, hrefs);
     if (e == hipSuccess) e = up(s->tplane, hp);
     if (e == hipSuccess) e = up(s->tedge, he);
     if (e == hipSuccess) e = up(s->mats, hm);
-    s->octree = !hon.empty();
+    s->octree = !hfn.empty();
     s->root_is_leaf = boxes[0].is_leaf != 0;
     s->why_generic = why;
-    if (e == hipSuccess && s->octree) e = up(s->onodes, hon);
+    if (e == hipSuccess && s->octree) e = up(s->fnodes, hfn);
     if (e == hipSuccess && s->octree) e = up(s->oblocks, hob);
     for (int k = 0; k < 2 && e == hipSuccess; k++) {
         e = s->w[k].ctrl.ensure(1);
@@ -895,32 +928,30 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     }
     if (e == hipSuccess) e = hipEventCreate(&s->fork_ev);
     if (e == hipSuccess) e = hipEventCreate(&s->end_ev);
-    if (e != hipSuccess) {
-        std::string msg = std::string("scene upload: ") + hipGetErrorString(e);
-        rtmi_scene_destroy(s);
-        return fail(e == hipErrorOutOfMemory ? RTMI_ERR_OOM : RTMI_ERR_NO_DEVICE, msg);
-    }
+    if (e != hipSuccess) return fail(hip_code(e), std::string("scene upload: ") + hipGetErrorString(e));
     s->d = DScene{s->nodes.p, s->refs.p, s->tplane.p, s->tedge.p, s->mats.p,
                   (uint32_t)nboxes, (uint32_t)ntris, (uint32_t)matmap.size(), levels,
-                  s->octree ? s->onodes.p : nullptr, s->octree ? s->oblocks.p : nullptr, boxes[0].len2, max_inner_depth + 1};
+                  s->octree ? s->fnodes.p : nullptr, s->octree ? s->oblocks.p : nullptr, boxes[0].len2, max_inner_depth + 1};
     if (s->octree) {
         s->oct_lds = (size_t)std::max<uint32_t>(1u, max_inner_depth) * 12 * 64;  // 3 words per level per lane
         if (s->oct_lds > 64 * 1024) { s->octree = false; s->why_generic = "octree deeper than the LDS stack allows"; }
         else {
             int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_oct<false>, 64, s->oct_lds) == hipSuccess && nb > 0)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_oct<false, false>, 64, s->oct_lds) == hipSuccess && nb > 0)
                 s->oct_blocks_per_cu = nb;
         }
     }
+    own.s = nullptr;
     *out = s;
     return RTMI_OK;
+    RTMI_GUARD_END
 }
 
 int rtmi_scene_destroy(rtmi_scene_t* s) {
     if (!s) return RTMI_OK;
     (void)hipSetDevice(s->device);
     s->nodes.release(); s->refs.release(); s->tplane.release(); s->tedge.release(); s->mats.release();
-    s->onodes.release(); s->oblocks.release();
+    s->fnodes.release(); s->oblocks.release();
     for (int k = 0; k < 2; k++) {
         s->w[k].release();
         if (s->istream[k]) (void)hipStreamDestroy(s->istream[k]);
@@ -939,6 +970,21 @@ int rtmi_scene_set_options(rtmi_scene_t* s, uint32_t options) {
     return RTMI_OK;
 }
 
+int rtmi_scene_get_tuning(rtmi_scene_t* s, rtmi_tuning_t* out) {
+    if (!s || !out) return fail(RTMI_ERR_INVALID, "NULL argument");
+    *out = s->tune;
+    return RTMI_OK;
+}
+
+int rtmi_scene_set_tuning(rtmi_scene_t* s, const rtmi_tuning_t* in) {
+    if (!s || !in) return fail(RTMI_ERR_INVALID, "NULL argument");
+    if (in->batch_paths == 0 || in->streams < 1 || in->streams > 2 || in->oct_waves_per_cu > 32 || in->refill_min0 < 1 ||
+        in->refill_min0 > 64 || in->refill_min < 1 || in->refill_min > 64 || in->xcd_aware > 2)
+        return fail(RTMI_ERR_INVALID, "tuning value out of range");
+    s->tune = *in;
+    return RTMI_OK;
+}
+
 static int ensure_workspace(Work& w, size_t cap, uint32_t maxdepth) {
     if (cap <= w.cap && maxdepth <= w.cap_depth) return RTMI_OK;
     cap = std::max(cap, w.cap);
@@ -950,7 +996,6 @@ static int ensure_workspace(Work& w, size_t cap, uint32_t maxdepth) {
     }
     HIPCHK(w.scol.ensure(cap));
     HIPCHK(w.hit_tf.ensure(cap));
-    HIPCHK(w.redo.ensure(cap));
     HIPCHK(w.hit_t.ensure(cap));
     HIPCHK(w.mstack.ensure(cap * (size_t)maxdepth));
     while (w.pass_ev.size() < 2 * (size_t)std::max<uint32_t>(maxdepth, 1u)) {
@@ -966,32 +1011,29 @@ static int ensure_workspace(Work& w, size_t cap, uint32_t maxdepth) {
 extern "C++" {
 template <bool COUNT>
 static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* qo, const float4* qd, int pass, hipEvent_t stop) {
-    // `stop` is recorded right after the closest-hit kernel proper (before the NaN-redo launch), so that the
-    // event pair of the caller times exactly the kernel rocprofv3 lists as k_trace_oct / k_trace_linear / k_trace
+    // `stop` is recorded right after the closest-hit kernel, so that the event pair of the caller times exactly
+    // the kernel rocprofv3 lists as k_trace_oct / k_trace_linear / k_trace
     if (s->root_is_leaf && !(s->options & RTMI_OPT_GENERIC)) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_linear<COUNT>), dim3((unsigned)(s->num_cu * 8)), dim3(256), 0, st, s->d, qo, qd,
                            w.ctrl.p, pass, w.hit_tf.p, w.hit_t.p);
-        (void)hipEventRecord(stop, st);
-        return;
+    } else if (s->octree && !(s->options & RTMI_OPT_GENERIC)) {
+        const int per_cu = s->tune.oct_waves_per_cu ? (int)s->tune.oct_waves_per_cu : s->oct_blocks_per_cu;
+        const dim3 grid((unsigned)(s->num_cu * per_cu)), block(64);
+        const int refill = (int)(pass == 0 ? s->tune.refill_min0 : s->tune.refill_min);
+        const int xcd = (int)(s->tune.xcd_aware % 3u);  // 1 = ranges by XCC_ID, 2 = by blockIdx % 8, 0 = one range
+        if (s->options & RTMI_OPT_FAST)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT, true>), grid, block, s->oct_lds, st, s->d, qo, qd, w.ctrl.p, pass,
+                               w.hit_tf.p, w.hit_t.p, refill, xcd);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT, false>), grid, block, s->oct_lds, st, s->d, qo, qd, w.ctrl.p, pass,
+                               w.hit_tf.p, w.hit_t.p, refill, xcd);
+    } else {
+        // persistent grid: enough blocks to fill every CU at the occupancy LDS allows
+        const int per_cu = s->trace_block == 256 ? 4 : 16;
+        const dim3 grid((unsigned)(s->num_cu * per_cu)), block((unsigned)s->trace_block);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<COUNT>), grid, block, s->trace_lds, st, s->d, qo, qd, w.ctrl.p, pass,
+                           w.hit_tf.p, w.hit_t.p);
     }
-    if (s->octree && !(s->options & RTMI_OPT_GENERIC)) {
-        const int per_cu = (int)env_size("RTMI_OCT_WAVES_PER_CU", (size_t)s->oct_blocks_per_cu);
-        dim3 grid((unsigned)(s->num_cu * per_cu)), block(64);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT>), grid, block, s->oct_lds, st, s->d, qo, qd, w.ctrl.p, pass,
-                           w.hit_tf.p, w.hit_t.p, w.redo.p, (int)(pass == 0 ? env_size("RTMI_REFILL_MIN0", 64) : env_size("RTMI_REFILL_MIN", 8)),
-                           (int)env_size("RTMI_XCD_AWARE", 1) % 3,   // 1 = ranges by XCC_ID, 2 = by blockIdx % 8, 3 -> 0 = one range
-                           (s->options & RTMI_OPT_FAST) ? 1 : 0);
-        (void)hipEventRecord(stop, st);
-        // exact re-trace of the (normally zero) rays whose leaf results contained a NaN hit time
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<false>), dim3(4), dim3((unsigned)s->trace_block), s->trace_lds, st, s->d, qo, qd,
-                           w.ctrl.p, pass, w.hit_tf.p, w.hit_t.p, (const uint32_t*)w.redo.p);
-        return;
-    }
-    // persistent grid: enough blocks to fill every CU at the occupancy LDS allows
-    const int per_cu = s->trace_block == 256 ? 4 : 16;
-    dim3 grid((unsigned)(s->num_cu * per_cu)), block((unsigned)s->trace_block);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace<COUNT>), grid, block, s->trace_lds, st, s->d, qo, qd, w.ctrl.p, pass,
-                       w.hit_tf.p, w.hit_t.p, (const uint32_t*)nullptr);
     (void)hipEventRecord(stop, st);
 }
 }  // extern "C++"
@@ -1058,8 +1100,8 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
         step = S;
     }
     const uint32_t nstripes = (nrows + S - 1) / S;
-    uint32_t nsub = (uint32_t)std::min<size_t>(env_size("RTMI_STREAMS", 2), 2);
-    if (nstripes < 2 || npix * spp < env_size("RTMI_SUBTILE_MIN_PATHS", 32768)) nsub = 1;
+    uint32_t nsub = std::min<uint32_t>(std::max<uint32_t>(s->tune.streams, 1u), 2u);
+    if (nstripes < 2 || npix * spp < s->tune.subtile_min_paths) nsub = 1;
     SubTile sub[2];
     for (uint32_t t = 0; t < nsub; t++) {
         DView& dv = sub[t].dv;
@@ -1076,7 +1118,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     }
 
     // batch = whole pixels with all their samples
-    const size_t want_paths = env_size("RTMI_BATCH_PATHS", (size_t)256 << 20) / nsub;
+    const size_t want_paths = (size_t)std::max<uint64_t>(s->tune.batch_paths, 1) / nsub;
     uint64_t pix_per_batch = std::max<uint64_t>(1, want_paths / spp);
     pix_per_batch = std::min<uint64_t>(pix_per_batch, std::max(sub[0].npix, sub[nsub - 1].npix));
     if (pix_per_batch * spp >= (1ull << 31)) return fail(RTMI_ERR_UNSUPPORTED, "batch above 2^31 paths");
@@ -1086,7 +1128,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     }
 
     const bool counting = (s->options & RTMI_OPT_COUNTERS) != 0;
-    const bool verbose = getenv("RTMI_VERBOSE") != nullptr;
+    const bool verbose = s->verbose;
     const unsigned ew_blocks = (unsigned)(s->num_cu * 8);
     float trace_ms = 0.f;
     uint32_t launches = 0;
@@ -1117,8 +1159,8 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
                     DCtrl hc2;
                     HIPCHK(hipMemcpyAsync(&hc2, w.ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost, st));
                     HIPCHK(hipStreamSynchronize(st));
-                    static unsigned long long prev[2][5 + 8];
-                    if (pass == 0) memset(prev[t], 0, sizeof(prev[t]));
+                    unsigned long long (*prev)[13] = s->vprev;
+                    if (pass == 0) memset(prev[t], 0, sizeof(s->vprev[t]));
                     unsigned long long cur[13];
                     for (int k = 0; k < 5; k++) cur[k] = hc2.counters[k];
                     for (int k = 0; k < 8; k++) cur[5 + k] = hc2.dbg[k];
@@ -1127,7 +1169,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
                             t, pass, (cur[0] - prev[t][0]) / n, (cur[1] - prev[t][1]) / n, (cur[2] - prev[t][2]) / n, (cur[3] - prev[t][3]) / n, (cur[4] - prev[t][4]) / n,
                             (cur[6] - prev[t][6]) / n, (double)(cur[6] - prev[t][6]) / (64.0 * (cur[5] - prev[t][5] ? cur[5] - prev[t][5] : 1)),
                             (cur[8] - prev[t][8]) / n, (double)(cur[8] - prev[t][8]) / (64.0 * (cur[7] - prev[t][7] ? cur[7] - prev[t][7] : 1)));
-                    memcpy(prev[t], cur, sizeof(prev[t]));
+                    memcpy(prev[t], cur, sizeof(s->vprev[t]));
                 }
                 hipLaunchKernelGGL(k_shade, dim3(ew_blocks), dim3(256), 0, st, s->d, dv, seed, pix0, npaths, (int)pass,
                                    w.qo[a].p, w.qd[a].p, w.qpath[a].p, w.hit_tf.p, w.hit_t.p, w.qo[b].p, w.qd[b].p,
@@ -1178,6 +1220,7 @@ int rtmi_render(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t seed, uint3
     HIPCHK(hipSetDevice(s->device));
     const uint64_t npix = (uint64_t)nrows * vp->width;
     if (npix == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return RTMI_OK; }
+    if ((uint64_t)row0 + nrows > vp->height) return fail(RTMI_ERR_INVALID, "row range outside the viewport");
     HIPCHK(s->tile.ensure(npix));
     int rc = rtmi_render_device(s, vp, seed, row0, nrows, s->tile.p, nullptr, stats);
     if (rc != RTMI_OK) return rc;
@@ -1192,6 +1235,7 @@ int rtmi_trace(rtmi_scene_t* s, uint64_t n, const float* orig4, const float* dir
     if (n == 0) return RTMI_OK;
     if (!orig4 || !dir4 || !tri || !t || !face) return fail(RTMI_ERR_INVALID, "NULL argument");
     if (n >= (1ull << 31)) return fail(RTMI_ERR_UNSUPPORTED, "more than 2^31 rays per call");
+    RTMI_GUARD_BEGIN
     HIPCHK(hipSetDevice(s->device));
     Work& w = s->w[0];
     int rc = ensure_workspace(w, (size_t)n, 1);
@@ -1216,6 +1260,7 @@ int rtmi_trace(rtmi_scene_t* s, uint64_t n, const float* orig4, const float* dir
     rc = read_stats(w, st, stats, ms, ms, 1);
     if (stats) stats->streams = 1;
     return rc;
+    RTMI_GUARD_END
 }
 
 // Development aid (not in rtmi.h): step statistics of the last counting render/trace.
@@ -1238,6 +1283,7 @@ int rtmi_make_triangles(int device, const float* corners9_host, uint64_t n, cons
     const int ndev = rtmi_device_count();
     if (ndev <= 0) return fail(RTMI_ERR_NO_DEVICE, "no HIP device visible: the MI355X kernels cannot run (there is no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(RTMI_ERR_INVALID, "device index out of range");
+    RTMI_GUARD_BEGIN
     HIPCHK(hipSetDevice(device));
     DevBuf<float> dpts, dout;
     DevBuf<uint32_t> dok;
@@ -1256,7 +1302,7 @@ int rtmi_make_triangles(int device, const float* corners9_host, uint64_t n, cons
     if (e == hipSuccess) e = hipMemcpy(rec.data(), dout.p, n * 20 * sizeof(float), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(ok.data(), dok.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
     cleanup();
-    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RTMI_ERR_OOM : RTMI_ERR_NO_DEVICE, std::string("rtmi_make_triangles: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(hip_code(e), std::string("rtmi_make_triangles: ") + hipGetErrorString(e));
     for (uint64_t i = 0; i < n; i++) {
         if (!ok[i]) return fail(RTMI_ERR_INVALID, "make_triangle: degenerate triangle " + std::to_string(i) + " (the reference panics at raytrace.rs:357)");
         rtmi_triangle_t t = *proto;
@@ -1266,6 +1312,7 @@ int rtmi_make_triangles(int device, const float* corners9_host, uint64_t n, cons
         out_host[i] = t;
     }
     return RTMI_OK;
+    RTMI_GUARD_END
 }
 
 int rtmi_quantize_device(rtmi_scene_t* s, const void* rgba_device, uint64_t npixels, void* rgb_device, void* hip_stream) {

@@ -67,6 +67,7 @@ int rth_add_triangle(rth_scene_t* s, const float* p, uint32_t kind, const float*
     return guarded([&] {
         const Vec3 pts[3] = {v3(p), v3(p + 3), v3(p + 6)};
         s->scene.tris.push_back(make_triangle(pts, surf(kind, c, alpha, scat), edge));
+        s->scene.touch();
     });
 }
 int rth_add_obj(rth_scene_t* s, const char* path, const float* off, float scale, const float* b9, uint32_t kind,
@@ -75,6 +76,7 @@ int rth_add_obj(rth_scene_t* s, const char* path, const float* off, float scale,
         auto t = obj_parser::parse_obj(path, v3(off), scale, std::make_tuple(v3(b9), v3(b9 + 3), v3(b9 + 6)),
                                        surf(kind, c, alpha, scat), edge);
         s->scene.tris.insert(s->scene.tris.end(), t.begin(), t.end());
+        s->scene.touch();
     });
 }
 int rth_add_disk(rth_scene_t* s, const float* orig3, const float* norm3, float r, float d, uint64_t n, uint32_t kind,
@@ -82,6 +84,7 @@ int rth_add_disk(rth_scene_t* s, const float* orig3, const float* norm3, float r
     return guarded([&] {
         auto t = make_disk(v3(orig3), v3(norm3), r, d, (size_t)n, surf(kind, c, alpha, scat), surf(skind, sc, salpha, sscat), edge);
         s->scene.tris.insert(s->scene.tris.end(), t.begin(), t.end());
+        s->scene.touch();
     });
 }
 int rth_add_sphere(rth_scene_t* s, const float* orig3, float r, uint64_t nlat, uint64_t nlon, uint32_t kind, const float* c,
@@ -89,6 +92,7 @@ int rth_add_sphere(rth_scene_t* s, const float* orig3, float r, uint64_t nlat, u
     return guarded([&] {
         auto t = make_sphere(v3(orig3), r, {(size_t)nlat, (size_t)nlon}, surf(kind, c, alpha, scat), edge);
         s->scene.tris.insert(s->scene.tris.end(), t.begin(), t.end());
+        s->scene.touch();
     });
 }
 int rth_add_triangles_gpu(rth_scene_t* s, const float* p, uint64_t n, uint32_t kind, const float* c, float alpha, float scat,
@@ -98,20 +102,21 @@ int rth_add_triangles_gpu(rth_scene_t* s, const float* p, uint64_t n, uint32_t k
         for (uint64_t i = 0; i < n * 3; i++) corners[i] = v3(p + 3 * i);
         auto t = make_triangles_gpu(corners, surf(kind, c, alpha, scat), edge, device);
         s->scene.tris.insert(s->scene.tris.end(), t.begin(), t.end());
+        s->scene.touch();
     });
 }
-void rth_populate_triangle_numbers(rth_scene_t* s) { populate_triangle_numbers(s->scene.tris); }
+void rth_populate_triangle_numbers(rth_scene_t* s) { populate_triangle_numbers(s->scene.tris); s->scene.touch(); }
 
 int rth_build_bounding_box(rth_scene_t* s, const float* orig3, float len2, uint64_t maxdepth, uint64_t minobjs, uint32_t threads) {
     return guarded([&] {
         s->scene.boxes = build_bounding_box(s->scene.tris, v3(orig3), len2, (size_t)maxdepth, (size_t)minobjs, threads);
-        if (s->caster) s->caster->invalidate();
+        s->scene.touch();
     });
 }
 int rth_build_trivial_bounding_box(rth_scene_t* s, const float* orig3, float len2) {
     return guarded([&] {
         s->scene.boxes = build_trivial_bounding_box(s->scene.tris, v3(orig3), len2);
-        if (s->caster) s->caster->invalidate();
+        s->scene.touch();
     });
 }
 int rth_box_contains_polygon(const rth_scene_t* s, const float* orig3, float len2, uint64_t tri) {
@@ -154,6 +159,12 @@ int rth_caster_config(rth_scene_t* s, uint64_t seed, int device, uint32_t option
         if (c.device != device) { c.invalidate(); c.device = device; }
         c.seed = seed;
         c.set_options(options);
+    });
+}
+int rth_caster_set_tuning(rth_scene_t* s, const rtmi_tuning_t* t) {
+    return guarded([&] {
+        if (t) caster_of(s).set_tuning(*t);
+        else caster_of(s).clear_tuning();
     });
 }
 int rth_caster_upload(rth_scene_t* s) { return guarded([&] { caster_of(s).resident(s->scene); }); }

@@ -485,13 +485,28 @@ HipRayCaster::HipRayCaster(uint64_t seed_, int device_) : seed(seed_), device(de
 HipRayCaster::~HipRayCaster() { invalidate(); }
 void HipRayCaster::invalidate() {
     if (handle_) rtmi_scene_destroy(handle_);
-    handle_ = nullptr; key_tris_ = nullptr;
+    handle_ = nullptr; key_scene_ = nullptr;
+}
+
+void HipRayCaster::apply_settings() {
+    rtmi_scene_set_options(handle_, options_);
+    rtmi_tuning_t t = defaults_;  // what rtmi_scene_create chose (environment or built-in)
+    if (!has_tuning_) { rtmi_scene_set_tuning(handle_, &t); return; }
+    // 0 = keep the library default (xcd_aware, where 0 is a value, is passed as given + 1)
+    if (tuning_.batch_paths) t.batch_paths = tuning_.batch_paths;
+    if (tuning_.streams) t.streams = tuning_.streams;
+    if (tuning_.subtile_min_paths) t.subtile_min_paths = tuning_.subtile_min_paths;
+    if (tuning_.oct_waves_per_cu) t.oct_waves_per_cu = tuning_.oct_waves_per_cu;
+    if (tuning_.refill_min0) t.refill_min0 = tuning_.refill_min0;
+    if (tuning_.refill_min) t.refill_min = tuning_.refill_min;
+    if (tuning_.xcd_aware) t.xcd_aware = tuning_.xcd_aware - 1;
+    if (rtmi_scene_set_tuning(handle_, &t) != RTMI_OK) throw std::runtime_error(std::string("rtmi_scene_set_tuning: ") + rtmi_last_error());
 }
 
 rtmi_scene_t* HipRayCaster::resident(const Scene& s) {
-    if (handle_ && key_tris_ == s.tris.data() && key_ntris_ == s.tris.size() && key_nboxes_ == s.boxes.boxes.size() &&
-        key_nrefs_ == s.boxes.tri_refs.size()) {
-        rtmi_scene_set_options(handle_, options_);
+    if (handle_ && key_scene_ == &s && key_generation_ == s.generation && key_ntris_ == s.tris.size() &&
+        key_nboxes_ == s.boxes.boxes.size() && key_nrefs_ == s.boxes.tri_refs.size()) {
+        apply_settings();
         return handle_;
     }
     invalidate();
@@ -503,9 +518,10 @@ rtmi_scene_t* HipRayCaster::resident(const Scene& s) {
                                      s.boxes.tri_refs.data(), s.boxes.tri_refs.size(), device, &h);
     if (rc != RTMI_OK) throw std::runtime_error(std::string("rtmi_scene_create: ") + rtmi_last_error());
     handle_ = h;
-    key_tris_ = s.tris.data(); key_ntris_ = s.tris.size();
+    rtmi_scene_get_tuning(handle_, &defaults_);
+    key_scene_ = &s; key_generation_ = s.generation; key_ntris_ = s.tris.size();
     key_nboxes_ = s.boxes.boxes.size(); key_nrefs_ = s.boxes.tri_refs.size();
-    rtmi_scene_set_options(handle_, options_);
+    apply_settings();
     return handle_;
 }
 

@@ -104,6 +104,10 @@ BoundingBox build_trivial_bounding_box(const std::vector<Triangle>& tris, const 
 struct Scene {
     std::vector<Triangle> tris;
     BoundingBox boxes;
+    // Bumped by touch(): a HipRayCaster keeps the uploaded copy of a Scene resident and re-uploads when the
+    // generation it saw differs.  Code that edits tris/boxes in place must call touch() afterwards.
+    uint64_t generation = 0;
+    void touch() { generation++; }
 };
 
 // raytrace.rs:1305-1318
@@ -153,16 +157,24 @@ public:
     void walk_tile_device(const Viewport& v, const Scene& s, const rtmi_tile_t& tile, void* out_device,
                           void* hip_stream, ProgressCtx& progress);
     void set_options(uint32_t opts) { options_ = opts; }
-    rtmi_scene_t* resident(const Scene& s);  // uploads on first use / when the scene changed
+    // Launch tuning (rtmi_tuning_t); fields left 0 keep the library defaults.  Never changes a pixel.
+    void set_tuning(const rtmi_tuning_t& t) { tuning_ = t; has_tuning_ = true; }
+    void clear_tuning() { has_tuning_ = false; }
+    // Uploads on first use, and again when another Scene object is passed or Scene::generation changed.
+    rtmi_scene_t* resident(const Scene& s);
     void invalidate();
     uint64_t seed;
     int device;
 
 private:
     rtmi_scene_t* handle_ = nullptr;
-    const void* key_tris_ = nullptr;
+    const Scene* key_scene_ = nullptr;
+    uint64_t key_generation_ = 0;
     size_t key_ntris_ = 0, key_nboxes_ = 0, key_nrefs_ = 0;
     uint32_t options_ = 0;
+    rtmi_tuning_t tuning_{}, defaults_{};
+    bool has_tuning_ = false;
+    void apply_settings();
 };
 
 void flatten_triangles(const std::vector<Triangle>& tris, std::vector<rtmi_triangle_t>& out);

@@ -192,11 +192,24 @@ class HipRayCaster:
     accepted and ignored, as the reference's CudaRayCaster does.
     """
 
-    def __init__(self, seed=1, device=0, options=0):
+    def __init__(self, seed=1, device=0, options=0, tuning=None):
+        """tuning: dict of rtmi_tuning_t fields (batch_paths, streams, subtile_min_paths, oct_waves_per_cu,
+        refill_min0, refill_min, xcd_aware); fields not given keep the library default.  Never changes a pixel."""
         self.seed, self.device, self.options = int(seed), int(device), int(options)
+        self.tuning = dict(tuning) if tuning else None
 
     def _config(self, s):
         _chk(_ffi.lib().rth_caster_config(s.h, self.seed, self.device, self.options))
+        if self.tuning is None:
+            if getattr(s, "_tuned", False):
+                _chk(_ffi.lib().rth_caster_set_tuning(s.h, None))
+                s._tuned = False
+        else:
+            t = _ffi.Tuning()
+            for k, v in self.tuning.items():
+                setattr(t, k, int(v) + 1 if k == "xcd_aware" else int(v))
+            _chk(_ffi.lib().rth_caster_set_tuning(s.h, C.byref(t)))
+            s._tuned = True
 
     def walk_rays(self, v, s, data, threads=1, show_progress=False):
         return self.walk_rows(v, s, 0, v.height, data)

@@ -204,16 +204,22 @@ def test_row_partition_invariance(canonical_pair):
     assert c.walk_rows(vp, sp, 5, 0, empty).total_rays == 0
 
 
-def test_small_batches_same_image(canonical_pair, monkeypatch):
+def test_small_batches_same_image(canonical_pair):
     so, sp = canonical_pair
     R = _R()
     vp = R.canonical_viewport(32, 32, 5, 4)
     a = np.zeros((32, 32, 4), np.float32)
     R.HipRayCaster(seed=3).walk_rays(vp, sp, a, 1, False)
-    monkeypatch.setenv("RTMI_BATCH_PATHS", "1000")  # forces many ragged batches
     b = np.zeros_like(a)
-    R.HipRayCaster(seed=3).walk_rays(vp, sp, b, 1, False)
+    R.HipRayCaster(seed=3, tuning={"batch_paths": 1000}).walk_rays(vp, sp, b, 1, False)  # forces many ragged batches
     assert_bits_equal(a, b, "batched")
+    # launch tuning never changes a pixel: waves per CU, refill thresholds, ray-queue ranges
+    for tn in ({"oct_waves_per_cu": 3, "refill_min0": 1, "refill_min": 64}, {"xcd_aware": 0}, {"xcd_aware": 2, "refill_min0": 17}):
+        c = np.zeros_like(a)
+        R.HipRayCaster(seed=3, tuning=tn).walk_rays(vp, sp, c, 1, False)
+        assert_bits_equal(a, c, f"tuning {tn}")
+    with pytest.raises(RuntimeError):
+        R.HipRayCaster(seed=3, tuning={"streams": 3}).walk_rays(vp, sp, b, 1, False)
 
 
 def test_quantize_matches_oracle(canonical_pair):
@@ -417,7 +423,7 @@ def test_odd_sizes_and_many_samples(circles_pair):
         assert ctx.total_rays == cn["rays"]
 
 
-def test_two_stream_subtiles_small_and_ragged(canonical_pair, monkeypatch):
+def test_two_stream_subtiles_small_and_ragged(canonical_pair):
     """The library splits a tile into two interleaved sub-tiles on two internal streams.  Force that on small,
     odd-sized images (partial last stripe, contiguous bands, striped tiles) and compare with the one-stream result."""
     import torch
@@ -428,9 +434,9 @@ def test_two_stream_subtiles_small_and_ragged(canonical_pair, monkeypatch):
         vo = orc.canonical_viewport(w, h)
         vp = R.canonical_viewport(w, h, 5, spp)
         ref, cn = so.render(w, h, vo, 5, spp, seed=4, threads=8)
-        monkeypatch.setenv("RTMI_SUBTILE_MIN_PATHS", "1")
+        two = {"subtile_min_paths": 1}
         img = np.zeros((h, w, 4), np.float32)
-        ctx = R.HipRayCaster(seed=4).walk_rays(vp, sp, img, 1, False)
+        ctx = R.HipRayCaster(seed=4, tuning=two).walk_rays(vp, sp, img, 1, False)
         assert ctx.stats["streams"] == (2 if h >= 2 else 1)
         assert_bits_equal(ref, img, f"two streams {w}x{h}")
         assert ctx.total_rays == cn["rays"]
@@ -438,15 +444,13 @@ def test_two_stream_subtiles_small_and_ragged(canonical_pair, monkeypatch):
         tile = rd.rank_tile(1, 3, h, 4)
         if tile[1]:
             buf = torch.zeros((tile[1], w, 4), dtype=torch.float32, device="cuda:0")
-            R.HipRayCaster(seed=4).walk_tile_device(vp, sp, tile, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            R.HipRayCaster(seed=4, tuning=two).walk_tile_device(vp, sp, tile, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             assert_bits_equal(ref[rd.tile_rows(tile, h)], buf.cpu().numpy(), f"striped two streams {w}x{h}")
-        monkeypatch.setenv("RTMI_STREAMS", "1")
         one = np.zeros((h, w, 4), np.float32)
-        ctx1 = R.HipRayCaster(seed=4).walk_rays(vp, sp, one, 1, False)
+        ctx1 = R.HipRayCaster(seed=4, tuning={"subtile_min_paths": 1, "streams": 1}).walk_rays(vp, sp, one, 1, False)
         assert ctx1.stats["streams"] == 1
         assert_bits_equal(ref, one, f"one stream {w}x{h}")
-        monkeypatch.delenv("RTMI_STREAMS")
 
 
 def test_fast_option_is_opt_in_and_close(canonical_pair):

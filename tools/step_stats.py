@@ -13,7 +13,7 @@ scene = R.canonical_scene(os.path.join(ROOT, "tests", "golden", "teapot_tri.obj"
 vp = R.canonical_viewport(W, H, 5, spp)
 c = R.HipRayCaster(seed=1, options=R.OPT_COUNTERS)
 img = np.zeros((H, W, 4), np.float32)
-os.environ["RTMI_BATCH_PATHS"] = str(1 << 30)
+
 ctx = c.walk_rays(vp, scene, img)
 print(ctx.stats)
 # the resident scene handle lives inside the C++ caster; fetch the debug counters through a tiny helper
