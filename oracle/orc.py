@@ -171,6 +171,15 @@ class Scene:
                                      C.c_int(threads), _p(out), _p(cn)))
         return out, dict(zip(COUNTER_NAMES, (int(x) for x in cn)))
 
+    def render_window(self, w, h, vp12, maxdepth, spp, row0, nrows, col0, ncols, seed=1, threads=1):
+        """Pixels [row0, row0+nrows) x [col0, col0+ncols) of the w x h frame -> (nrows, ncols, 4), counters."""
+        out = np.zeros((nrows, ncols, 4), np.float32)
+        cn = np.zeros(6, np.uint64)
+        self._check(lib().orc_render_window(self.h, C.c_uint32(w), C.c_uint32(h), _p(_f(vp12)), C.c_uint64(maxdepth),
+                                            C.c_uint64(spp), C.c_uint64(seed), C.c_uint64(row0), C.c_uint64(nrows),
+                                            C.c_uint64(col0), C.c_uint64(ncols), C.c_int(threads), _p(out), _p(cn)))
+        return out, dict(zip(COUNTER_NAMES, (int(x) for x in cn)))
+
     def trace(self, o4, d4):
         o4, d4 = _f(o4).reshape(-1, 4), _f(d4).reshape(-1, 4)
         n = o4.shape[0]

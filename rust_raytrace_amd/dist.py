@@ -45,34 +45,72 @@ def max_rows(world, height, stripe_rows=DEFAULT_STRIPE_ROWS):
     return max(len(tile_rows_for(r, world, height, stripe_rows)) for r in range(world))
 
 
+class FrameGather:
+    """The single gather of a frame + the de-interleave, with everything that does not depend on pixel values built
+    once: receive buffer ((world, max_rows, W, C), one slab per rank: gather_list entries are views of it), the padded
+    send band, and the row permutation as ONE index tensor, so a frame costs one collective and one indexed copy.
+
+    `local` bands are (rows_r, W, C) on the rank's device: C = 4 f32 (the reference's `[Color]`) or C = 3 u8 (already
+    quantised with HipRayCaster.quantize_device: 3 bytes per pixel over the links instead of 16)."""
+
+    def __init__(self, rank, world, height, width, stripe_rows=DEFAULT_STRIPE_ROWS, channels=4, dtype=None, device=None,
+                 dst=0, group=None):
+        import torch
+        import torch.distributed as dist
+        self.rank, self.world, self.h, self.w, self.s, self.c, self.dst, self.group = rank, world, height, width, stripe_rows, channels, dst, group
+        self.dtype = dtype or torch.float32
+        self.device = device
+        self.host = world > 1 and dist.get_backend(group) == "gloo"  # gloo moves host memory (CPU tests, rehearsals)
+        self.mr = max_rows(world, height, stripe_rows)
+        self.nrows = len(tile_rows_for(rank, world, height, stripe_rows))
+        xdev = "cpu" if self.host else device
+        self.send = None
+        if world > 1 and self.nrows != self.mr:
+            self.send = torch.zeros((self.mr, width, channels), dtype=self.dtype, device=xdev)
+        self.recv = None
+        self.frame = None
+        if rank == dst:
+            self.frame = torch.empty((height, width, channels), dtype=self.dtype, device=device)
+            if world > 1:
+                self.recv = torch.empty((world, self.mr, width, channels), dtype=self.dtype, device=xdev)
+            # frame row of every (rank, local row) slot of the receive buffer, and which slots are real rows
+            src, dstrow = [], []
+            for r in range(world):
+                rows = tile_rows_for(r, world, height, stripe_rows)
+                src.extend(range(r * self.mr, r * self.mr + len(rows)))
+                dstrow.extend(rows.tolist())
+            order = np.argsort(np.asarray(dstrow))
+            assert len(dstrow) == height and np.array_equal(np.asarray(dstrow)[order], np.arange(height))
+            self.src_of_row = torch.as_tensor(np.asarray(src, dtype=np.int64)[order], device=device)
+
+    def __call__(self, local):
+        """Collective on every rank; returns the (H, W, C) frame on `dst`, None elsewhere."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            self.frame.copy_(local)  # one rank holds every row, in order
+            return self.frame
+        band = local
+        if self.host and band.is_cuda:
+            band = band.cpu()
+        if self.send is not None:
+            self.send[: self.nrows].copy_(band)
+            band = self.send
+        band = band.contiguous()
+        bands = [self.recv[r] for r in range(self.world)] if self.rank == self.dst else None
+        dist.gather(band, bands, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        flat = self.recv.view(self.world * self.mr, self.w, self.c)
+        if self.host:
+            flat = flat.to(self.device)
+        torch.index_select(flat, 0, self.src_of_row, out=self.frame)  # de-interleave: one indexed copy
+        return self.frame
+
+
 def gather_frame(local, rank, world, height, width, stripe_rows=DEFAULT_STRIPE_ROWS, dst=0, group=None):
-    """Collect the per-rank bands on `dst` and return the (H, W, C) frame there (None elsewhere).
-
-    `local` is a torch tensor (rows_r, W, C) on the rank's device: C = 4 f32 (the reference's `[Color]`) or
-    C = 3 u8 (already quantised with HipRayCaster.quantize_device: 3 bytes per pixel over the links instead
-    of 16).  One gather of equal-sized (padded) bands, then an index copy on the root."""
-    import torch
-    import torch.distributed as dist
-
-    ch = local.shape[2]
-    if world == 1:
-        frame = torch.empty((height, width, ch), dtype=local.dtype, device=local.device)
-        frame[torch.as_tensor(tile_rows_for(0, 1, height, stripe_rows), device=local.device)] = local
-        return frame
-    mr = max_rows(world, height, stripe_rows)
-    send = local
-    if local.shape[0] != mr:
-        send = torch.zeros((mr, width, ch), dtype=local.dtype, device=local.device)
-        send[: local.shape[0]] = local
-    send = send.contiguous()
-    if dist.get_backend(group) == "gloo" and send.is_cuda:
-        send = send.cpu()  # gloo moves host memory (CPU tests, and rehearsing N ranks on one GPU)
-    bands = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, bands, dst=dst, group=group)
-    if rank != dst:
-        return None
-    frame = torch.empty((height, width, ch), dtype=local.dtype, device=local.device)
-    for r in range(world):
-        rows = tile_rows_for(r, world, height, stripe_rows)
-        frame[torch.as_tensor(rows, device=local.device)] = bands[r][: len(rows)].to(local.device)
-    return frame
+    """One-shot form of FrameGather (tests, tools): collect the per-rank bands on `dst`, return the (H, W, C) frame there."""
+    g = FrameGather(rank, world, height, width, stripe_rows, channels=local.shape[2], dtype=local.dtype, device=local.device,
+                    dst=dst, group=group)
+    f = g(local)
+    return None if f is None else f.clone()

@@ -394,17 +394,24 @@ def test_quantize_device_matches_oracle(canonical_pair):
 
 
 def test_make_triangles_gpu(canonical_pair):
-    # the GPU make_triangle kernel against the host computation: every record of the canonical scene, bit for bit
+    # the GPU make_triangle kernel (k_make_triangles) against the ORACLE's make_triangle (raytrace.rs:340-383): every
+    # record of the canonical scene, bit for bit, and against the committed fixture written from the oracle
+    import os
+    from conftest import GOLDEN
     R = _R()
-    _, sp = canonical_pair
-    rec, kinds, surf = sp.triangles()
+    so, _ = canonical_pair
+    rec, kinds, surf = so.triangles()
     s = R.Scene(False)
     matte = R.SurfaceKind.Matte(R.make_color(252, 119, 0), 0.2)
     s.extend_make_triangles_gpu(rec[:, 20:29].reshape(-1, 3, 3), matte, 0.05)
     got, _, _ = s.triangles()
     assert got.shape == rec.shape
-    assert_bits_equal(got[:, :19], rec[:, :19], "geometric fields")  # incenter norm r2 sides side_lens
+    assert_bits_equal(got[:, :19], rec[:, :19], "geometric fields vs oracle")  # incenter norm r2 sides side_lens
     assert_bits_equal(got[:, 20:], rec[:, 20:], "corners")
+    z = np.load(os.path.join(GOLDEN, "canonical_triangle_records.npz"))
+    idx = z["idx"]
+    idx = idx[idx != 0]  # record 0 is make_dummy_triangle(), not a make_triangle() result
+    assert_bits_equal(got[idx][:, :19], z["rec"][z["idx"] != 0][:, :19], "geometric fields vs golden fixture")
     with pytest.raises(RuntimeError, match="degenerate triangle 1"):
         s.extend_make_triangles_gpu(np.array([[[0, 0, 1], [1, 0, 1], [0, 1, 1]], [[0, 0, 0], [0, 0, 0], [0, 0, 0]]], np.float32), matte, 0.0)
 
@@ -487,3 +494,127 @@ def test_full_size_config3_sample_rows_vs_oracle(canonical_pair):
         ctx = c.walk_rows(vp, sp, row, 1, got)
         assert_bits_equal(ref, got, f"row {row}")
         assert ctx.total_rays == cn["rays"], row
+
+
+# ---------------------------------------------------------------- BASELINE configs 4 and 5 at their stated sizes
+# image features of the canonical view (64 x 64 first-hit map in tests/golden): teapot rows 25-46, mirror disk A at
+# cols 41-60 / rows 14-29, mirror disk B at cols 9-19 / rows 14-25, sky elsewhere; x 64 for a 4096 x 4096 frame.
+_C4_WINDOWS = [  # (rank of 8, first row, first col) of 8 x 32 pixel windows; row // 16 % 8 == rank
+    (0, 2048, 2000),   # teapot body
+    (2, 1952, 1264),   # teapot spout / silhouette
+    (3, 1200, 3072),   # mirror disk A (reflective, scattering 0.0002)
+    (7, 1136, 768),    # mirror disk B (reflective, scattering 0.002)
+    (5, 80, 0),        # sky
+]
+
+
+def test_full_size_config4_windows_vs_oracle(canonical_pair):
+    """BASELINE config 4 at its stated size (4096 x 4096 @ 256 spp, depth 5, seed 1, image tiled over 8 ranks in
+    interleaved 16-row stripes): the WHOLE tile of a rank is rendered through its rtmi_tile_t (one eighth of the
+    frame, ~750 M rays) and pixel windows on the teapot, both mirror disks and the sky are compared with the oracle
+    bit for bit (the oracle cannot render 4.3 G samples; it renders the windows, orc_render_window)."""
+    import os
+    import torch
+    from rust_raytrace_amd import dist as rd
+    so, sp = canonical_pair
+    orc, R = _orc(), _R()
+    W = H = 4096
+    spp = 256
+    vo = orc.canonical_viewport(W, H)
+    vp = R.canonical_viewport(W, H, 5, spp)
+    c = R.HipRayCaster(seed=1)
+    threads = max(1, len(os.sched_getaffinity(0)))
+    st = torch.cuda.current_stream().cuda_stream
+    for rank, row0, col0 in _C4_WINDOWS:
+        tile = rd.rank_tile(rank, 8, H, 16)
+        rows = rd.tile_rows(tile, H)
+        assert (row0 // 16) % 8 == rank
+        buf = torch.zeros((tile[1], W, 4), dtype=torch.float32, device="cuda:0")
+        ctx = c.walk_tile_device(vp, sp, tile, buf.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert ctx.total_rays >= tile[1] * W * spp
+        lr = int(np.nonzero(rows == row0)[0][0])  # local row of the window's first row inside the rank's buffer
+        got = buf[lr:lr + 8, col0:col0 + 32].cpu().numpy()
+        del buf
+        ref, _ = so.render_window(W, H, vo, 5, spp, row0, 8, col0, 32, seed=1, threads=threads)
+        assert_bits_equal(ref, got, f"config 4 window rank {rank} rows {row0}.. cols {col0}..")
+
+
+def test_full_size_config4_tiles_reproduce_frame(canonical_pair):
+    """4096 x 4096 (config 4's frame, 2 spp to stay in seconds): the 8 interleaved 16-row-stripe tiles, de-interleaved,
+    equal the single-tile frame bit for bit; ray counts add up."""
+    import torch
+    from rust_raytrace_amd import dist as rd
+    _, sp = canonical_pair
+    R = _R()
+    W = H = 4096
+    vp = R.canonical_viewport(W, H, 5, 2)
+    c = R.HipRayCaster(seed=1)
+    st = torch.cuda.current_stream().cuda_stream
+    whole = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    total = c.walk_tile_device(vp, sp, (0, H, H, 0), whole.data_ptr(), st).total_rays
+    frame = torch.zeros_like(whole)
+    rays = 0
+    for r in range(8):
+        tile = rd.rank_tile(r, 8, H, 16)
+        buf = torch.zeros((tile[1], W, 4), dtype=torch.float32, device="cuda:0")
+        rays += c.walk_tile_device(vp, sp, tile, buf.data_ptr(), st).total_rays
+        torch.cuda.synchronize()
+        frame[torch.as_tensor(rd.tile_rows(tile, H), device="cuda:0")] = buf
+    assert rays == total
+    assert torch.equal(frame.view(torch.int32), whole.view(torch.int32))
+
+
+def test_full_size_config5_grid_rows_vs_oracle():
+    """BASELINE config 5 at its stated octree (maxdepth 10, minobjs 19; 8 x teapot_tri.obj = 50 561 triangles,
+    ~1.6 M boxes, depth-10 LDS stack) and size (2048 x 2048 @ 64 spp): the tree is built by the product's builder
+    (bit-equal to the oracle's on CPU: tests/test_host_cpu.py) and handed to the oracle with orc_set_tree, so the
+    single-threaded oracle builder is not needed.  Sampled rows, image bits and all six work counters."""
+    import os
+    from conftest import OracleApi, ProductApi, TEAPOT_TRI
+    orc, R = _orc(), _R()
+    threads = max(1, len(os.sched_getaffinity(0)))
+    sp = R.grid_scene(TEAPOT_TRI, threads=threads)
+    # the same triangles on the oracle side, no tree build there
+    so = recipe_grid_no_tree()(OracleApi(orc))
+    assert so.num_tris() == sp.num_tris() == 8 * 6320 + 1
+    ro, _, _ = so.triangles()
+    rp, _, _ = sp.triangles()
+    assert_bits_equal(ro, rp, "triangle records")
+    geo, topo, refs = sp.tree()
+    assert int(topo[:, 3].max()) == 10
+    so.set_tree(geo, topo, refs)
+    W = H = 2048
+    vo = orc.canonical_viewport(W, H)
+    vp = R.canonical_viewport(W, H, 5, 64)
+    c = R.HipRayCaster(seed=1, options=R.OPT_COUNTERS)
+    bounced = 0
+    for row in (420, 1024, 1290, 1700):
+        ref, cn = so.render(W, H, vo, 5, 64, seed=1, row0=row, nrows=1, threads=threads)
+        got = np.zeros((1, W, 4), np.float32)
+        ctx = c.walk_rows(vp, sp, row, 1, got)
+        assert_bits_equal(ref, got, f"config 5 row {row}")
+        for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
+            assert ctx.stats[k] == cn[k], (row, k)
+        bounced += cn["rays"] - W * 64
+    assert bounced > 0  # the sampled rows do cross the teapots
+
+
+def recipe_grid_no_tree():
+    """recipe_grid() without the bounding-box build."""
+    from conftest import TEAPOT_TRI
+
+    def r(api):
+        s = api.scene()
+        surfs = [api.matte((252, 119, 0), 0.2), api.reflective(0.01, (200, 200, 220), 0.6), api.solid((30, 160, 60)),
+                 api.matte((200, 40, 40), 0.35)]
+        k = 0
+        for iz in range(2):
+            for iy in range(2):
+                for ix in range(2):
+                    off = [-4.5 + 9.0 * ix, -4.5 + 9.0 * iy, 9.0 + 9.0 * iz]
+                    api.add_obj(s, TEAPOT_TRI, off, 1.0, api.transform([0.0, 0.3, 1.0], 270.0 + 20.0 * k), surfs[k % 4], 0.05 if k % 2 == 0 else 0.0)
+                    k += 1
+        s.populate_triangle_numbers()
+        return s
+    return r

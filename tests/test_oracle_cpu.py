@@ -118,3 +118,20 @@ def test_quantize_is_rust_as_u8():
     x = np.array([[0.0, 1.0, 0.5, 0], [-1.0, 2.0, np.nan, 0], [0.999, 1e-9, np.inf, 0], [254.9 / 255, 255.1 / 255, -np.inf, 0]], np.float32)
     q = orc.quantize(x)
     assert q.tolist() == [[0, 255, 127], [0, 255, 0], [254, 0, 255], [254, 255, 0]]
+
+
+def test_render_window_equals_rows():
+    """orc_render_window (pixel windows for the full-size config-4 checks) is the same per-pixel loop as orc_render."""
+    import pytest
+    from conftest import TEAPOT_TRI
+    orc = _orc()
+    so = orc.canonical_scene(TEAPOT_TRI, maxdepth=6)
+    vo = orc.canonical_viewport(64, 48)
+    rows, cr = so.render(64, 48, vo, 5, 3, seed=9, row0=20, nrows=6, threads=4)
+    win, cw = so.render_window(64, 48, vo, 5, 3, 20, 6, 10, 30, seed=9, threads=3)
+    assert_bits_equal(rows[:, 10:40], win, "window")
+    full, cf = so.render_window(64, 48, vo, 5, 3, 20, 6, 0, 64, seed=9, threads=2)
+    assert_bits_equal(rows, full, "full-width window")
+    assert cf == cr and cw["rays"] < cr["rays"]
+    with pytest.raises(RuntimeError):
+        so.render_window(64, 48, vo, 5, 3, 44, 6, 0, 64)

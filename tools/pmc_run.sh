@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/pmc_run.sh <tag> <bench args...>   (run on the GPU box through gpurun)
+# usage: RTMI_COMMIT=<sha> [RTMI_PMC_CONFIG='{json}'] tools/pmc_run.sh <tag> <bench args...>   (run on the GPU box through gpurun)
 # Separate rocprofv3 --pmc passes (no tracing domains combined with counters), CSV output under gpurun_out/.
 tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
@@ -14,4 +14,4 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_W
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $out/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-counters "$@" > $out/p$i.log 2>&1 || echo "pass $i failed: $(tail -2 $out/p$i.log)"
 done
-python3 $GRAFT_REPO_ROOT/tools/pmc_summarize.py $out
+python3 $GRAFT_REPO_ROOT/tools/pmc_summarize.py $out ${RTMI_PMC_CONFIG:+"$RTMI_PMC_CONFIG"}
