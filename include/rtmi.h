@@ -158,6 +158,22 @@ int rtmi_render_tile_device(rtmi_scene_t* scene, const rtmi_viewport_t* vp, uint
                             const rtmi_tile_t* tile, void* out_device, void* hip_stream,
                             rtmi_stats_t* stats);
 
+/* One whole frame over several devices of this process -- the fan-out the reference does over CPU threads
+ * (DefaultRayCaster::walk_rays_internal, raytrace.rs:1175-1196: `threads` workers pulling rows from a queue) done
+ * over GPUs, inside the library.  scenes[i] is the SAME scene uploaded to some device (rtmi_scene_create with
+ * device = i; two handles may also share a device).  Scene i renders the interleaved stripes
+ * {i*S, rows_i, S, n*S} (S = stripe_rows, 0 = default 16) on its own host thread and stream; every band then
+ * crosses to scenes[0]'s device ONCE (hipMemcpyPeerAsync: one xGMI link per peer, all links at the same time),
+ * where a kernel de-interleaves the stripes into the frame.  No other exchange: pixels are independent and the RNG
+ * is keyed by (pixel, sample), so the frame is bit-identical to rtmi_render() of the whole image on one device.
+ * flags: RTMI_FRAME_RGB8 quantises every band on its device first ((c*255.) as u8, raytrace.rs:1468-1473), so
+ * 3 bytes per pixel cross the links instead of 16 and the output is height*width*3 bytes; otherwise the output is
+ * height*width*4 floats (`[Color]`).  out_host and/or out_device (memory of scenes[0]'s device) receive the frame.
+ * stats (optional) has nscenes entries, one per scene; "Rays" of the frame is their sum. */
+enum { RTMI_FRAME_RGB8 = 1u << 0 };
+int rtmi_render_frame_multi(rtmi_scene_t* const* scenes, uint32_t nscenes, const rtmi_viewport_t* vp, uint64_t seed,
+                            uint32_t stripe_rows, uint32_t flags, void* out_host, void* out_device, rtmi_stats_t* stats);
+
 /* Closest hit for n explicit rays: orig (x,y,z,lane3) and unit dir
  * (x,y,z,lane3) as `make_ray` stores them (raytrace.rs:201-210).  Outputs per
  * ray: triangle index (0 = miss), hit time, face (0 front, 1 back, 2 edge

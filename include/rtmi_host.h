@@ -72,6 +72,13 @@ int rth_caster_walk_tile_device(rth_scene_t* s, uint32_t w, uint32_t h, const fl
                                 double* wall_seconds);
 int rth_caster_trace(rth_scene_t* s, uint64_t n, const float* orig4, const float* dir4, uint32_t* tri, float* t,
                      uint32_t* face, rtmi_stats_t* stats);
+/* Multi-GPU inside the process (rtmi_render_frame_multi): the caster keeps one resident copy of the scene per entry of
+ * `devices` (an entry may repeat a device); entry 0 is the root that receives the bands.  With more than one entry
+ * walk_rays (rth_caster_walk_rows over the whole image) and rth_caster_walk_frame_multi stripe the frame over them. */
+int rth_caster_set_devices(rth_scene_t* s, const int32_t* devices, uint32_t n);
+int rth_caster_walk_frame_multi(rth_scene_t* s, uint32_t w, uint32_t h, const float* vp12, uint64_t maxdepth, uint64_t spp,
+                                uint32_t stripe_rows, uint32_t flags /* RTMI_FRAME_RGB8 */, void* out_host, void* out_device,
+                                rtmi_stats_t* stats_sum, rtmi_stats_t* per_device, uint32_t per_device_cap, double* wall_seconds);
 int rth_caster_upload(rth_scene_t* s);
 /* Launch tuning for this scene's caster: fields that are 0 keep the library default, xcd_aware is passed as value + 1;
  * NULL restores all defaults.  Never changes a pixel. */

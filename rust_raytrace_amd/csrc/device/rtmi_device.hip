@@ -29,6 +29,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -626,6 +627,20 @@ __global__ void __launch_bounds__(256) k_quantize(uint64_t npixels, const float4
     }
 }
 
+// rtmi_render_frame_multi: bands of the n scenes, each padded to `mr` rows, lie one after the other in `stage`;
+// image row `row` is local row (row / (S*n)) * S + row % S of band (row / S) % n.  `px` = bytes per pixel (16 or 3).
+__global__ void __launch_bounds__(256) k_deinterleave(const uint8_t* __restrict__ stage, uint8_t* __restrict__ out, uint32_t W,
+                                                      uint32_t H, uint32_t S, uint32_t n, uint32_t mr, uint32_t px) {
+    const uint64_t npix = (uint64_t)W * H, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
+        const uint32_t row = (uint32_t)(p / W), col = (uint32_t)(p - (uint64_t)row * W);
+        const uint32_t band = (row / S) % n, lr = (row / (S * n)) * S + row % S;
+        const uint64_t src = (((uint64_t)band * mr + lr) * W + col) * px;
+        if (px == 16) *reinterpret_cast<float4*>(out + p * 16) = *reinterpret_cast<const float4*>(stage + src);
+        else { out[p * 3] = stage[src]; out[p * 3 + 1] = stage[src + 1]; out[p * 3 + 2] = stage[src + 2]; }
+    }
+}
+
 // Explicit-ray entry (rtmi_trace): queue = the caller's rays
 __global__ void k_set_count(DCtrl* ctrl, uint32_t n) { ctrl->count[0] = n; }
 
@@ -713,6 +728,8 @@ struct rtmi_scene {
     hipEvent_t fork_ev = nullptr, end_ev = nullptr, join_ev[2] = {nullptr, nullptr};
     DevBuf<float4> tile;
     DevBuf<uint8_t> qbytes;
+    DevBuf<uint8_t> mstage, mframe;  // rtmi_render_frame_multi, root scene: received bands / the frame
+    hipStream_t mstream = nullptr;   // rtmi_render_frame_multi: this scene's band stream
     int num_cu = 256;
     int trace_block = 256;
     size_t trace_lds = 0;
@@ -959,7 +976,8 @@ int rtmi_scene_destroy(rtmi_scene_t* s) {
     }
     if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
     if (s->end_ev) (void)hipEventDestroy(s->end_ev);
-    s->tile.release(); s->qbytes.release();
+    s->tile.release(); s->qbytes.release(); s->mstage.release(); s->mframe.release();
+    if (s->mstream) (void)hipStreamDestroy(s->mstream);
     delete s;
     return RTMI_OK;
 }
@@ -1226,6 +1244,86 @@ int rtmi_render(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t seed, uint3
     if (rc != RTMI_OK) return rc;
     HIPCHK(hipMemcpy(out_host, s->tile.p, npix * sizeof(float4), hipMemcpyDeviceToHost));
     return RTMI_OK;
+}
+
+int rtmi_render_frame_multi(rtmi_scene_t* const* scenes, uint32_t nscenes, const rtmi_viewport_t* vp, uint64_t seed,
+                            uint32_t stripe_rows, uint32_t flags, void* out_host, void* out_device, rtmi_stats_t* stats) {
+    if (!scenes || nscenes == 0 || !vp) return fail(RTMI_ERR_INVALID, "NULL argument");
+    if (nscenes > 64) return fail(RTMI_ERR_UNSUPPORTED, "more than 64 scene handles");
+    for (uint32_t i = 0; i < nscenes; i++) {
+        if (!scenes[i]) return fail(RTMI_ERR_INVALID, "scene handle is NULL");
+        for (uint32_t j = 0; j < i; j++)
+            if (scenes[j] == scenes[i]) return fail(RTMI_ERR_INVALID, "the same scene handle is listed twice (one render in flight per handle)");
+    }
+    if (!out_host && !out_device) return fail(RTMI_ERR_INVALID, "out_host and out_device are both NULL");
+    if (vp->width == 0 || vp->height == 0) return fail(RTMI_ERR_INVALID, "empty viewport");
+    if (flags & ~(uint32_t)RTMI_FRAME_RGB8) return fail(RTMI_ERR_INVALID, "unknown flag");
+    RTMI_GUARD_BEGIN
+    const uint32_t W = vp->width, H = vp->height, n = nscenes;
+    const uint32_t S = stripe_rows ? stripe_rows : 16u;
+    const bool rgb8 = (flags & RTMI_FRAME_RGB8) != 0;
+    const uint32_t px = rgb8 ? 3u : 16u;
+    // rows of scene i: stripes i, i+n, i+2n, ... of S rows (the last stripe of the image may be short)
+    std::vector<uint32_t> rows(n, 0);
+    for (uint32_t k = 0; (uint64_t)k * S < H; k++) rows[k % n] += std::min<uint32_t>(S, H - k * S);
+    const uint32_t mr = *std::max_element(rows.begin(), rows.end());
+    rtmi_scene* root = scenes[0];
+    HIPCHK(hipSetDevice(root->device));
+    HIPCHK(root->mstage.ensure((size_t)n * mr * W * px));
+    if (!out_device) { HIPCHK(root->mframe.ensure((size_t)H * W * px)); }
+    uint8_t* frame = out_device ? (uint8_t*)out_device : root->mframe.p;
+
+    // ---- fan-out: one host thread per scene handle renders its tile and sends the band to the root device
+    std::vector<int> rcs(n, RTMI_OK);
+    std::vector<std::string> errs(n);
+    std::vector<rtmi_stats_t> sts(n);
+    auto work = [&](uint32_t i) {
+        rtmi_scene* sc = scenes[i];
+        rtmi_stats_t& st = sts[i];
+        memset(&st, 0, sizeof(st));
+        auto bail = [&](int rc, const std::string& msg) { rcs[i] = rc; errs[i] = msg; };
+        if (rows[i] == 0) return;
+        hipError_t e = hipSetDevice(sc->device);
+        if (e == hipSuccess && sc->device != root->device) {  // direct xGMI copies to the root instead of staging through the host
+            const hipError_t pe = hipDeviceEnablePeerAccess(root->device, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();  // copies still work, slower
+        }
+        if (e == hipSuccess && !sc->mstream) e = hipStreamCreateWithFlags(&sc->mstream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = sc->tile.ensure((size_t)rows[i] * W);
+        if (e == hipSuccess && rgb8) e = sc->qbytes.ensure((size_t)rows[i] * W * 3);
+        if (e != hipSuccess) return bail(hip_code(e), std::string("rtmi_render_frame_multi: ") + hipGetErrorString(e));
+        const rtmi_tile_t tile{i * S, rows[i], S, n * S};
+        int rc = rtmi_render_tile_device(sc, vp, seed, &tile, sc->tile.p, sc->mstream, &st);
+        if (rc != RTMI_OK) return bail(rc, g_err);
+        const void* band = sc->tile.p;
+        if (rgb8) {
+            hipLaunchKernelGGL(k_quantize, dim3((unsigned)(sc->num_cu * 8)), dim3(256), 0, sc->mstream, (uint64_t)rows[i] * W,
+                               (const float4*)sc->tile.p, sc->qbytes.p);
+            band = sc->qbytes.p;
+        }
+        // the single crossing of this band: its own link to the root (a plain device copy when both are one device)
+        e = hipMemcpyPeerAsync(root->mstage.p + (size_t)i * mr * W * px, root->device, band, sc->device, (size_t)rows[i] * W * px, sc->mstream);
+        if (e == hipSuccess) e = hipStreamSynchronize(sc->mstream);
+        if (e != hipSuccess) return bail(hip_code(e), std::string("rtmi_render_frame_multi: band copy: ") + hipGetErrorString(e));
+    };
+    if (n == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (uint32_t i = 0; i < n; i++) th.emplace_back(work, i);
+        for (auto& t : th) t.join();
+    }
+    for (uint32_t i = 0; i < n; i++)
+        if (rcs[i] != RTMI_OK) return fail(rcs[i], "scene " + std::to_string(i) + ": " + errs[i]);
+    // ---- root: de-interleave the stripes into the frame
+    HIPCHK(hipSetDevice(root->device));
+    if (!root->mstream) HIPCHK(hipStreamCreateWithFlags(&root->mstream, hipStreamNonBlocking));
+    hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)(root->num_cu * 8)), dim3(256), 0, root->mstream, root->mstage.p, frame, W, H, S, n, mr, px);
+    HIPCHK(hipGetLastError());
+    if (out_host) HIPCHK(hipMemcpyAsync(out_host, frame, (size_t)H * W * px, hipMemcpyDeviceToHost, root->mstream));
+    HIPCHK(hipStreamSynchronize(root->mstream));
+    if (stats) memcpy(stats, sts.data(), sizeof(rtmi_stats_t) * n);
+    return RTMI_OK;
+    RTMI_GUARD_END
 }
 
 int rtmi_trace(rtmi_scene_t* s, uint64_t n, const float* orig4, const float* dir4, uint32_t* tri, float* t,

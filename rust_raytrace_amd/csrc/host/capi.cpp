@@ -161,6 +161,23 @@ int rth_caster_config(rth_scene_t* s, uint64_t seed, int device, uint32_t option
         c.set_options(options);
     });
 }
+int rth_caster_set_devices(rth_scene_t* s, const int32_t* devices, uint32_t n) {
+    return guarded([&] { caster_of(s).set_devices(std::vector<int>(devices, devices + n)); });
+}
+int rth_caster_walk_frame_multi(rth_scene_t* s, uint32_t w, uint32_t h, const float* vp12, uint64_t maxdepth, uint64_t spp,
+                                uint32_t stripe_rows, uint32_t flags, void* out_host, void* out_device, rtmi_stats_t* stats,
+                                rtmi_stats_t* per_device, uint32_t per_device_cap, double* wall) {
+    return guarded([&] {
+        const Viewport v = vp_from(w, h, vp12, maxdepth, spp);
+        ProgressCtx ctx;
+        std::vector<rtmi_stats_t> pd;
+        const auto t0 = std::chrono::steady_clock::now();
+        caster_of(s).walk_frame_multi(v, s->scene, out_host, out_device, stripe_rows, flags, ctx, &pd);
+        if (wall) *wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (stats) *stats = ctx.stats;
+        for (uint32_t k = 0; per_device && k < per_device_cap && k < pd.size(); k++) per_device[k] = pd[k];
+    });
+}
 int rth_caster_set_tuning(rth_scene_t* s, const rtmi_tuning_t* t) {
     return guarded([&] {
         if (t) caster_of(s).set_tuning(*t);

@@ -485,11 +485,21 @@ HipRayCaster::HipRayCaster(uint64_t seed_, int device_) : seed(seed_), device(de
 HipRayCaster::~HipRayCaster() { invalidate(); }
 void HipRayCaster::invalidate() {
     if (handle_) rtmi_scene_destroy(handle_);
+    for (rtmi_scene_t* h : extra_) rtmi_scene_destroy(h);
+    extra_.clear();
     handle_ = nullptr; key_scene_ = nullptr;
+}
+
+void HipRayCaster::set_devices(const std::vector<int>& devices) {
+    if (devices == devices_) return;
+    invalidate();
+    devices_ = devices;
+    if (!devices_.empty()) device = devices_[0];
 }
 
 void HipRayCaster::apply_settings() {
     rtmi_scene_set_options(handle_, options_);
+    for (rtmi_scene_t* h : extra_) rtmi_scene_set_options(h, options_);
     rtmi_tuning_t t = defaults_;  // what rtmi_scene_create chose (environment or built-in)
     if (!has_tuning_) { rtmi_scene_set_tuning(handle_, &t); return; }
     // 0 = keep the library default (xcd_aware, where 0 is a value, is passed as given + 1)
@@ -518,6 +528,16 @@ rtmi_scene_t* HipRayCaster::resident(const Scene& s) {
                                      s.boxes.tri_refs.data(), s.boxes.tri_refs.size(), device, &h);
     if (rc != RTMI_OK) throw std::runtime_error(std::string("rtmi_scene_create: ") + rtmi_last_error());
     handle_ = h;
+    for (size_t k = 1; k < devices_.size(); k++) {  // one more resident copy per extra device
+        rtmi_scene_t* e = nullptr;
+        if (rtmi_scene_create(flat.data(), flat.size(), s.boxes.boxes.data(), s.boxes.boxes.size(), s.boxes.tri_refs.data(),
+                              s.boxes.tri_refs.size(), devices_[k], &e) != RTMI_OK) {
+            const std::string msg = std::string("rtmi_scene_create (device ") + std::to_string(devices_[k]) + "): " + rtmi_last_error();
+            invalidate();
+            throw std::runtime_error(msg);
+        }
+        extra_.push_back(e);
+    }
     rtmi_scene_get_tuning(handle_, &defaults_);
     key_scene_ = &s; key_generation_ = s.generation; key_ntris_ = s.tris.size();
     key_nboxes_ = s.boxes.boxes.size(); key_nrefs_ = s.boxes.tri_refs.size();
@@ -555,8 +575,33 @@ void HipRayCaster::walk_rows(const Viewport& v, const Scene& s, size_t row0, siz
     progress.stats = st;
 }
 
+void HipRayCaster::walk_frame_multi(const Viewport& v, const Scene& s, void* data_host, void* data_device, uint32_t stripe_rows,
+                                    uint32_t flags, ProgressCtx& progress, std::vector<rtmi_stats_t>* per_device) {
+    rtmi_scene_t* h = resident(s);
+    std::vector<rtmi_scene_t*> hs{h};
+    hs.insert(hs.end(), extra_.begin(), extra_.end());
+    const rtmi_viewport_t av = to_abi(v);
+    std::vector<rtmi_stats_t> st(hs.size());
+    const int rc = rtmi_render_frame_multi(hs.data(), (uint32_t)hs.size(), &av, seed, stripe_rows, flags, data_host, data_device, st.data());
+    if (rc != RTMI_OK) throw std::runtime_error(std::string("rtmi_render_frame_multi: ") + rtmi_last_error());
+    rtmi_stats_t sum{};
+    for (const rtmi_stats_t& d : st) {
+        sum.rays += d.rays; sum.box_tests += d.box_tests; sum.tri_tests += d.tri_tests; sum.full_tests += d.full_tests;
+        sum.nodes += d.nodes; sum.leaves += d.leaves; sum.trace_ms += d.trace_ms; sum.trace_launches += d.trace_launches;
+        sum.kernel_ms = std::max(sum.kernel_ms, d.kernel_ms);  // the devices run concurrently
+        sum.streams = std::max(sum.streams, d.streams);
+    }
+    progress.total_rays += sum.rays;
+    progress.kernel_seconds += sum.kernel_ms * 1e-3;
+    progress.stats = sum;
+    if (per_device) *per_device = st;
+}
+
+// DefaultRayCaster fans rows out over `threads` CPU threads (raytrace.rs:1175-1196); here the fan-out is over the
+// caster's devices, inside the library.  `threads` is ignored like the reference's CudaRayCaster does.
 void HipRayCaster::walk_rays_internal(const Viewport& v, const Scene& s, Color* data, size_t /*threads*/, ProgressCtx& progress) {
-    walk_rows(v, s, 0, v.height, data, progress);
+    if (devices_.size() > 1) walk_frame_multi(v, s, data, nullptr, 0, 0, progress);
+    else walk_rows(v, s, 0, v.height, data, progress);
 }
 
 void quantize_rgb8(const Color* data, size_t npixels, uint8_t* rgb) {

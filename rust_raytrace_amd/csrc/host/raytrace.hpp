@@ -153,6 +153,13 @@ public:
     void walk_rows(const Viewport& v, const Scene& s, size_t row0, size_t nrows, Color* data, ProgressCtx& progress);
     void walk_rows_device(const Viewport& v, const Scene& s, size_t row0, size_t nrows, void* out_device,
                           void* hip_stream, ProgressCtx& progress);
+    // Multi-GPU inside one process (rtmi_render_frame_multi): the frame is striped over `devices` (one uploaded copy
+    // of the scene per entry; an entry may repeat a device), bands are copied once to devices[0] and de-interleaved
+    // there.  With more than one entry walk_rays_internal() takes this path.  flags: RTMI_FRAME_RGB8 -> `data` is
+    // height*width*3 bytes.
+    void set_devices(const std::vector<int>& devices);
+    void walk_frame_multi(const Viewport& v, const Scene& s, void* data_host, void* data_device, uint32_t stripe_rows,
+                          uint32_t flags, ProgressCtx& progress, std::vector<rtmi_stats_t>* per_device = nullptr);
     // Striped row set (rtmi_tile_t): rank r of N renders {r*S, H/N, S, N*S}.
     void walk_tile_device(const Viewport& v, const Scene& s, const rtmi_tile_t& tile, void* out_device,
                           void* hip_stream, ProgressCtx& progress);
@@ -168,6 +175,8 @@ public:
 
 private:
     rtmi_scene_t* handle_ = nullptr;
+    std::vector<int> devices_;                 // multi-GPU: device of every extra handle (entry 0 = `device`)
+    std::vector<rtmi_scene_t*> extra_;         // handles of devices_[1..]
     const Scene* key_scene_ = nullptr;
     uint64_t key_generation_ = 0;
     size_t key_ntris_ = 0, key_nboxes_ = 0, key_nrefs_ = 0;

@@ -192,14 +192,22 @@ class HipRayCaster:
     accepted and ignored, as the reference's CudaRayCaster does.
     """
 
-    def __init__(self, seed=1, device=0, options=0, tuning=None):
+    def __init__(self, seed=1, device=0, options=0, tuning=None, devices=None):
         """tuning: dict of rtmi_tuning_t fields (batch_paths, streams, subtile_min_paths, oct_waves_per_cu,
-        refill_min0, refill_min, xcd_aware); fields not given keep the library default.  Never changes a pixel."""
+        refill_min0, refill_min, xcd_aware); fields not given keep the library default.  Never changes a pixel.
+        devices: list of device indices for the in-library multi-GPU fan-out (rtmi_render_frame_multi); entry 0 is the
+        root, an entry may repeat a device.  With more than one entry walk_rays() stripes the frame over them."""
         self.seed, self.device, self.options = int(seed), int(device), int(options)
         self.tuning = dict(tuning) if tuning else None
+        self.devices = [int(d) for d in devices] if devices else None
+        if self.devices:
+            self.device = self.devices[0]
 
     def _config(self, s):
         _chk(_ffi.lib().rth_caster_config(s.h, self.seed, self.device, self.options))
+        devs = self.devices or [self.device]
+        arr = (C.c_int32 * len(devs))(*devs)
+        _chk(_ffi.lib().rth_caster_set_devices(s.h, arr, len(devs)))
         if self.tuning is None:
             if getattr(s, "_tuned", False):
                 _chk(_ffi.lib().rth_caster_set_tuning(s.h, None))
@@ -212,7 +220,28 @@ class HipRayCaster:
             s._tuned = True
 
     def walk_rays(self, v, s, data, threads=1, show_progress=False):
+        if self.devices and len(self.devices) > 1:
+            return self.walk_frame_multi(v, s, data)
         return self.walk_rows(v, s, 0, v.height, data)
+
+    def walk_frame_multi(self, v, s, data=None, rgb8=False, stripe_rows=0, out_device_ptr=None):
+        """One frame striped over self.devices inside the library.  data: (H, W, 4) f32, or (H, W, 3) u8 with rgb8=True
+        (each band is quantised on its device before it crosses to the root).  Returns ProgressCtx; .per_device holds the
+        stats of every device."""
+        want = (np.uint8, 3) if rgb8 else (np.float32, 4)
+        if data is not None and (data.dtype != want[0] or not data.flags.c_contiguous or data.size != v.height * v.width * want[1]):
+            raise ValueError("data must be C-contiguous (H, W, 4) float32, or (H, W, 3) uint8 with rgb8")
+        self._config(s)
+        n = len(self.devices or [self.device])
+        st = _ffi.Stats()
+        per = (_ffi.Stats * n)()
+        wall = C.c_double(0)
+        _chk(_ffi.lib().rth_caster_walk_frame_multi(s.h, v.width, v.height, _p(v.vp12), v.maxdepth, v.samples_per_pixel, stripe_rows,
+                                                    1 if rgb8 else 0, _p(data) if data is not None else None,
+                                                    C.c_void_p(out_device_ptr or 0), C.byref(st), per, n, C.byref(wall)))
+        ctx = ProgressCtx(st.rays, wall.value, st.as_dict())
+        ctx.per_device = [p.as_dict() for p in per]
+        return ctx
 
     def walk_rows(self, v, s, row0, nrows, data):
         """Rows [row0, row0+nrows) only — the unit of multi-GPU image tiling."""

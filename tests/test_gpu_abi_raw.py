@@ -234,3 +234,49 @@ def test_deep_chain_tree(options):
         assert cn["nodes"] > cn["rays"]  # the chain is really descended
     finally:
         L.rtmi_scene_destroy(h)
+
+
+def test_render_frame_multi_raw_abi():
+    """rtmi_render_frame_multi through the raw C ABI: ONE handle (n = 1), then THREE handles of the same scene on the one
+    GPU of the test box (three stripes sets, three host threads, three band copies to the root, de-interleave kernel),
+    f32 and RGB8 output; each equals rtmi_render of the whole image bit for bit (and the oracle), ray counts add up.
+    Height 45 with 4-row stripes: ragged last stripe, unequal band sizes."""
+    from oracle import orc
+    L, ffi = _lib()
+    L.rtmi_render_frame_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
+    so = recipe_circles()(OracleApi(orc))
+    tris, geo, topo, refs = _abi_arrays(so)
+    boxes = _boxes(geo, topo)
+    hs = []
+    for _ in range(3):
+        rc, h = _create(L, tris, boxes, refs)
+        assert rc == RTMI_OK
+        hs.append(h)
+    w, hgt, spp, seed = 37, 45, 3, 8
+    vp12 = orc.canonical_viewport(w, hgt)
+    ref, cn = so.render(w, hgt, vp12, 5, spp, seed=seed, threads=8)
+    whole, st1 = _render(L, ffi, hs[0], vp12, w, hgt, 5, spp, seed)
+    assert_bits_equal(ref, whole, "single-device render vs oracle")
+    vp = Vp(w, hgt, (C.c_float * 3)(*vp12[0:3]), (C.c_float * 3)(*vp12[3:6]), (C.c_float * 3)(*vp12[6:9]), (C.c_float * 3)(*vp12[9:12]), 5, spp)
+    for n, S in ((1, 0), (3, 4), (2, 16), (3, 1)):
+        arr = (C.c_void_p * n)(*[h.value for h in hs[:n]])
+        out = np.zeros((hgt, w, 4), np.float32)
+        sts = (ffi.Stats * n)()
+        rc = L.rtmi_render_frame_multi(arr, n, C.byref(vp), seed, S, 0, out.ctypes.data_as(C.c_void_p), None, sts)
+        assert rc == RTMI_OK, L.rtmi_last_error()
+        assert_bits_equal(whole, out, f"multi n={n} S={S}")
+        assert sum(s.rays for s in sts) == st1.rays == cn["rays"]
+        q = np.zeros((hgt, w, 3), np.uint8)
+        rc = L.rtmi_render_frame_multi(arr, n, C.byref(vp), seed, S, 1, q.ctypes.data_as(C.c_void_p), None, None)
+        assert rc == RTMI_OK, L.rtmi_last_error()
+        assert np.array_equal(q.reshape(-1, 3), orc.quantize(ref)), f"rgb8 n={n} S={S}"
+    # errors: the same handle twice, no output, unknown flag
+    arr = (C.c_void_p * 2)(hs[0].value, hs[0].value)
+    out = np.zeros((hgt, w, 4), np.float32)
+    assert L.rtmi_render_frame_multi(arr, 2, C.byref(vp), seed, 4, 0, out.ctypes.data_as(C.c_void_p), None, None) == RTMI_ERR_INVALID
+    arr = (C.c_void_p * 1)(hs[0].value)
+    assert L.rtmi_render_frame_multi(arr, 1, C.byref(vp), seed, 4, 0, None, None, None) == RTMI_ERR_INVALID
+    assert L.rtmi_render_frame_multi(arr, 1, C.byref(vp), seed, 4, 8, out.ctypes.data_as(C.c_void_p), None, None) == RTMI_ERR_INVALID
+    for h in hs:
+        L.rtmi_scene_destroy(h)

@@ -618,3 +618,30 @@ def recipe_grid_no_tree():
         s.populate_triangle_numbers()
         return s
     return r
+
+
+def test_caster_multi_device_fanout_in_library(canonical_pair):
+    """HipRayCaster with a device list: walk_rays() stripes the frame over the caster's devices INSIDE the library
+    (rtmi_render_frame_multi; the fan-out DefaultRayCaster does over threads, raytrace.rs:1175-1196).  The test box has
+    one GPU, so the list names it twice (two resident copies, two host threads); the frame equals the single-device
+    one and the oracle bit for bit, also as RGB8 (each band quantised on its device before it crosses to the root)."""
+    so, sp = canonical_pair
+    orc, R = _orc(), _R()
+    w, h, spp = 64, 50, 2
+    vo = orc.canonical_viewport(w, h)
+    vp = R.canonical_viewport(w, h, 5, spp)
+    ref, cn = so.render(w, h, vo, 5, spp, seed=12, threads=8)
+    img = np.zeros((h, w, 4), np.float32)
+    ctx = R.HipRayCaster(seed=12, devices=[0, 0]).walk_rays(vp, sp, img, 1, False)
+    assert_bits_equal(ref, img, "two handles on one device")
+    assert ctx.total_rays == cn["rays"]
+    assert len(ctx.per_device) == 2 and all(d["rays"] > 0 for d in ctx.per_device)
+    q = np.zeros((h, w, 3), np.uint8)
+    R.HipRayCaster(seed=12, devices=[0, 0]).walk_frame_multi(vp, sp, q, rgb8=True, stripe_rows=8)
+    assert np.array_equal(q.reshape(-1, 3), orc.quantize(ref))
+    # back to one device: same scene object, the caster drops the extra copy
+    one = np.zeros_like(img)
+    R.HipRayCaster(seed=12).walk_rays(vp, sp, one, 1, False)
+    assert_bits_equal(ref, one, "single device again")
+    with pytest.raises(RuntimeError):
+        R.HipRayCaster(seed=12, devices=[0, 99]).walk_rays(vp, sp, img, 1, False)
