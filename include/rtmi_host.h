@@ -39,6 +39,10 @@ uint64_t rth_num_tris(const rth_scene_t* s);
 int rth_add_triangle(rth_scene_t* s, const float* pts9, uint32_t kind, const float* color3, float alpha, float scattering, float edge);
 int rth_add_obj(rth_scene_t* s, const char* path, const float* offset3, float scale, const float* basis9,
                 uint32_t kind, const float* color3, float alpha, float scattering, float edge);
+/* The same with robust != 0: opt-in loader extension (fan-triangulated polygons, negative indices, degenerate
+ * triangles skipped).  robust == 0 is the reference's loader (first three corners, obj_parser.rs:63-65). */
+int rth_add_obj_mode(rth_scene_t* s, const char* path, const float* offset3, float scale, const float* basis9, uint32_t kind,
+                     const float* color3, float alpha, float scattering, float edge_thickness, uint32_t robust);
 int rth_add_disk(rth_scene_t* s, const float* orig3, const float* norm3, float r, float d, uint64_t num_tris,
                  uint32_t kind, const float* color3, float alpha, float scattering,
                  uint32_t side_kind, const float* side_color3, float side_alpha, float side_scattering, float edge);

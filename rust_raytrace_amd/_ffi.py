@@ -81,6 +81,7 @@ def lib():
     L.rth_add_triangle.argtypes = [vp, vp, u32, vp, f32, f32, f32]
     L.rth_add_triangles_gpu.argtypes = [vp, vp, u64, u32, vp, f32, f32, f32, i32]
     L.rth_add_obj.argtypes = [vp, C.c_char_p, vp, f32, vp, u32, vp, f32, f32, f32]
+    L.rth_add_obj_mode.argtypes = [vp, C.c_char_p, vp, f32, vp, u32, vp, f32, f32, f32, u32]
     L.rth_add_disk.argtypes = [vp, vp, vp, f32, f32, u64, u32, vp, f32, f32, u32, vp, f32, f32, f32]
     L.rth_add_sphere.argtypes = [vp, vp, f32, u64, u64, u32, vp, f32, f32, f32]
     L.rth_populate_triangle_numbers.argtypes = [vp]
@@ -111,7 +112,7 @@ RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_scene_create", "rtmi_scene_destroy", 
                 "rtmi_scene_get_tuning", "rtmi_scene_set_tuning", "rtmi_render", "rtmi_render_frame_multi",
                 "rtmi_render_device", "rtmi_render_tile_device", "rtmi_trace", "rtmi_quantize", "rtmi_quantize_device", "rtmi_make_triangles", "rtmi_last_error"]
 RTH_SYMBOLS = ["rth_last_error", "rth_make_color", "rth_unit", "rth_to_radians", "rth_create_transform",
-               "rth_create_viewport", "rth_scene_new", "rth_scene_free", "rth_num_tris", "rth_add_triangle", "rth_add_triangles_gpu", "rth_add_obj",
+               "rth_create_viewport", "rth_scene_new", "rth_scene_free", "rth_num_tris", "rth_add_triangle", "rth_add_triangles_gpu", "rth_add_obj", "rth_add_obj_mode",
                "rth_add_disk", "rth_add_sphere", "rth_populate_triangle_numbers", "rth_build_bounding_box",
                "rth_build_trivial_bounding_box", "rth_box_contains_polygon", "rth_face_contains_triangle",
                "rth_get_triangles", "rth_tree_sizes", "rth_tree_get", "rth_caster_config", "rth_caster_walk_rows",

@@ -72,9 +72,13 @@ int rth_add_triangle(rth_scene_t* s, const float* p, uint32_t kind, const float*
 }
 int rth_add_obj(rth_scene_t* s, const char* path, const float* off, float scale, const float* b9, uint32_t kind,
                 const float* c, float alpha, float scat, float edge) {
+    return rth_add_obj_mode(s, path, off, scale, b9, kind, c, alpha, scat, edge, 0);
+}
+int rth_add_obj_mode(rth_scene_t* s, const char* path, const float* off, float scale, const float* b9, uint32_t kind,
+                     const float* c, float alpha, float scat, float edge, uint32_t robust) {
     return guarded([&] {
         auto t = obj_parser::parse_obj(path, v3(off), scale, std::make_tuple(v3(b9), v3(b9 + 3), v3(b9 + 6)),
-                                       surf(kind, c, alpha, scat), edge);
+                                       surf(kind, c, alpha, scat), edge, robust ? obj_parser::ObjMode::Robust : obj_parser::ObjMode::Reference);
         s->scene.tris.insert(s->scene.tris.end(), t.begin(), t.end());
         s->scene.touch();
     });

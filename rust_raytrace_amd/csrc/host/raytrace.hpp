@@ -190,10 +190,13 @@ void flatten_triangles(const std::vector<Triangle>& tris, std::vector<rtmi_trian
 rtmi_viewport_t to_abi(const Viewport& v);
 
 namespace obj_parser {
-// obj_parser.rs:47-73
+// obj_parser.rs:47-73.  ObjMode::Reference (default) is the reference's loader exactly: first three corners of every
+// face, 1-based positive indices.  ObjMode::Robust is an opt-in extension: polygons are fan-triangulated, negative
+// (relative) indices are resolved, degenerate triangles are skipped.
+enum class ObjMode { Reference = 0, Robust = 1 };
 std::vector<Triangle> parse_obj(const std::string& path, const Vec3& offset, float scale,
                                 const std::tuple<Vec3, Vec3, Vec3>& transform, const SurfaceKind& surface,
-                                float edge_thickness);
+                                float edge_thickness, ObjMode mode = ObjMode::Reference);
 }  // namespace obj_parser
 
 // raytrace.rs:1460-1478: quantisation only ((c*255.) as u8); PNG encoding stays with the caller.

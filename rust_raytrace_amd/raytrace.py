@@ -116,10 +116,11 @@ class Scene:
         pts = _f(points).reshape(-1, 9)
         _chk(_ffi.lib().rth_add_triangles_gpu(self.h, _p(pts), pts.shape[0], *surface.args(), edge_thickness, device))
 
-    def extend_parse_obj(self, path, offset, scale, transform, surface, edge_thickness):
-        """obj_data.extend(obj_parser::parse_obj(...)) — obj_parser.rs:47-73"""
-        _chk(_ffi.lib().rth_add_obj(self.h, path.encode(), _p(_f(offset)), scale, _p(_f(transform)), *surface.args(),
-                                    edge_thickness))
+    def extend_parse_obj(self, path, offset, scale, transform, surface, edge_thickness, robust=False):
+        """obj_data.extend(obj_parser::parse_obj(...)) — obj_parser.rs:47-73.  robust=True is an opt-in loader extension
+        (fan-triangulated polygons, negative indices, degenerate triangles skipped); the default is the reference's loader."""
+        _chk(_ffi.lib().rth_add_obj_mode(self.h, path.encode(), _p(_f(offset)), scale, _p(_f(transform)), *surface.args(),
+                                         edge_thickness, 1 if robust else 0))
 
     def extend_make_disk(self, orig, norm, r, d, num_tris, surface, side_surface, edge_thickness):
         """obj_data.extend(make_disk(...)) — raytrace.rs:531-592"""

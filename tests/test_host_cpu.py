@@ -159,3 +159,43 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in text.replace("# oracle", "").lower() or f in (), f"{f} mentions the oracle"
     for hdr in os.listdir(os.path.join(ROOT, "include")):
         assert "oracle" not in open(os.path.join(ROOT, "include", hdr)).read().lower()
+
+
+def test_obj_loader_default_is_reference_and_robust_is_opt_in(tmp_path):
+    """obj_parser.rs:47-73: the default loader takes the FIRST THREE corners of a face and 1-based positive indices
+    (bit-equal to the oracle's restatement).  robust=True is an opt-in extension the reference does not have (parity
+    unpinned by definition): polygons fan-triangulated, negative indices resolved, degenerate triangles skipped."""
+    from oracle import orc
+    from rust_raytrace_amd import raytrace as R
+    quad = tmp_path / "quad.obj"
+    quad.write_text("# a quad, a pentagon and a triangle with relative indices\n"
+                    "v 0 0 5\nv 1 0 5\nv 1 1 5\nv 0 1 5\nv 0.5 1.5 5\n"
+                    "f 1 2 3 4\nf 1/1/1 2/2/2 3/3/3 5/5/5 4/4/4\nvn 0 0 1\n"
+                    "v 2 0 6\nv 3 0 6\nv 2 1 6\nf -3 -2 -1\n")
+    tri = tmp_path / "tri.obj"
+    tri.write_text("v 0 0 5\nv 1 0 5\nv 1 1 5\nv 0 1 5\nv 0.5 1.5 5\nv 2 0 6\nv 3 0 6\nv 2 1 6\n"
+                   "f 1 2 3\nf 1 3 4\nf 1 2 3\nf 1 3 5\nf 1 5 4\nf 6 7 8\n")
+    basis = R.create_transform(R.unit([0.0, 0.3, 1.0]), R.to_radians(20.0))
+    m = R.SurfaceKind.Matte(R.make_color(10, 20, 30), 0.4)
+
+    def load(path, robust):
+        s = R.Scene(False)
+        s.extend_parse_obj(str(path), [0.5, 0.0, 1.0], 2.0, basis, m, 0.05, robust=robust)
+        return s.triangles()[0]
+    # robust on the polygon file == reference loader on the hand-triangulated file
+    assert_bits_equal(load(quad, True), load(tri, False), "fan triangulation + negative indices")
+    # the default on the triangulated file is the oracle's parse_obj
+    so = orc.Scene(False)
+    so.add_obj(str(tri), [0.5, 0.0, 1.0], 2.0, orc.create_transform(orc.unit([0.0, 0.3, 1.0]), orc.to_radians(20.0)),
+               orc.Surface(orc.MATTE, orc.make_color(10, 20, 30), 0.4), 0.05)
+    assert_bits_equal(so.triangles()[0], load(tri, False), "reference loader vs oracle")
+    # the default on the polygon file: first three corners of the quad and of the pentagon, then it rejects "-3"
+    # exactly where the reference's `parse::<usize>().unwrap()` panics
+    with pytest.raises(RuntimeError, match="bad index"):
+        load(quad, False)
+    first = tmp_path / "first3.obj"
+    first.write_text("v 0 0 5\nv 1 0 5\nv 1 1 5\nv 0 1 5\nf 1 2 3 4\n")
+    assert load(first, False).shape[0] == 1 and load(first, True).shape[0] == 2
+    # the teapot has only triangles: both modes give the same records
+    a, b = load(TEAPOT_TRI, False), load(TEAPOT_TRI, True)
+    assert_bits_equal(a, b, "teapot, both modes")
