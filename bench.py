@@ -136,13 +136,14 @@ def main():
 
     obj = os.path.join(ROOT, "tests", "golden", "teapot_tri.obj")
     t0 = time.time()
-    build_threads = max(1, len(os.sched_getaffinity(0)) // max(world, 1))  # ranks of one node share the host cores
+    # the octree is built with the overlap tests on this rank's GPU (rtmi_builder_*; bit-equal to the host build), so
+    # the ranks of a node do not compete for host cores
     if args.scene == "grid":
-        scene = R.grid_scene(obj, threads=build_threads)
+        scene = R.grid_scene(obj, gpu_build=local_rank)
     elif args.scene == "linear":
         scene = R.canonical_scene(os.path.join(ROOT, "tests", "golden", "teapot.obj"), accel="trivial")
     else:
-        scene = R.canonical_scene(obj, threads=build_threads)  # octree (10, 19)
+        scene = R.canonical_scene(obj, gpu_build=local_rank)  # octree (10, 19)
     t_build = time.time() - t0
     W, H, spp = args.width, args.height, args.spp
     vp = R.canonical_viewport(W, H, args.maxdepth, spp)

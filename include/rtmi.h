@@ -122,7 +122,7 @@ int rtmi_scene_set_options(rtmi_scene_t* scene, uint32_t options);
 
 /* Launch tuning of one scene handle.  Defaults are taken ONCE, at rtmi_scene_create(), from the environment
  * (RTMI_BATCH_PATHS, RTMI_STREAMS, RTMI_SUBTILE_MIN_PATHS, RTMI_OCT_WAVES_PER_CU, RTMI_REFILL_MIN0,
- * RTMI_REFILL_MIN, RTMI_XCD_AWARE; RTMI_VERBOSE=1 prints per-pass timings to stderr) and can be read and changed
+ * RTMI_REFILL_MIN, RTMI_XCD_AWARE, RTMI_KERNEL; RTMI_VERBOSE=1 prints per-pass timings to stderr) and can be read and changed
  * here.  None of them changes a pixel: any batch size, stream count or stripe split gives the same image. */
 typedef struct rtmi_tuning {
     uint64_t batch_paths;       /* paths (pixel samples) per batch of the wavefront pipeline; default 256 Mi  */
@@ -132,7 +132,8 @@ typedef struct rtmi_tuning {
     uint32_t refill_min0;       /* idle lanes before a wave refills, primary pass (64 = whole wave); default 64 */
     uint32_t refill_min;        /* the same for bounce passes; default 8                                       */
     uint32_t xcd_aware;         /* 1 = one ray-queue range per XCD (by XCC_ID), 2 = by block index, 0 = one queue */
-    uint32_t reserved;
+    uint32_t kernel;            /* octree closest-hit kernel: 0 = automatic, 1 = one ray per lane (k_trace_oct),
+                                 * 2 = per-wave ray pool in LDS (k_trace_pool; falls back to 1 for very deep trees) */
 } rtmi_tuning_t;
 int rtmi_scene_get_tuning(rtmi_scene_t* scene, rtmi_tuning_t* out);
 int rtmi_scene_set_tuning(rtmi_scene_t* scene, const rtmi_tuning_t* in);
@@ -195,6 +196,26 @@ int rtmi_quantize_device(rtmi_scene_t* scene, const void* rgba_device, uint64_t 
  * the reference panics on a degenerate triangle (unwrap at raytrace.rs:357). */
 int rtmi_make_triangles(int device, const float* corners9_host, uint64_t n, const rtmi_triangle_t* proto,
                         rtmi_triangle_t* out_host);
+
+/* Octree build on the GPU (raytrace.rs:753-845).  The builder's whole cost is box_contains_polygon (raytrace.rs:753-779)
+ * on every (candidate child box, triangle of the parent's list) pair; rtmi_builder_filter evaluates it for all pairs of
+ * one tree level, bit-identical to the host computation, so the resulting tree equals the reference builder's.  The
+ * caller keeps the list bookkeeping (which is linear): see build_bounding_box_gpu in csrc/host/raytrace.cpp.
+ * tris15: ntris x 15 floats (incenter, norm, corner 0, corner 1, corner 2), kept on the device by the handle.
+ * boxes[b]: geometry + the range [cand_first, cand_first + cand_count) of `cand` (triangle indices) to test against it;
+ * keep[keep_first + j] receives 1 when box b contains candidate j, else 0.  Ranges of different boxes may overlap in
+ * `cand` (the 8 children of a box share their parent's list) but not in `keep`. */
+typedef struct rtmi_build_box {
+    float orig[3];
+    float len2;
+    uint32_t cand_first, cand_count;
+    uint64_t keep_first;
+} rtmi_build_box_t;
+typedef struct rtmi_builder rtmi_builder_t;
+int rtmi_builder_create(int device, const float* tris15, uint64_t ntris, rtmi_builder_t** out);
+int rtmi_builder_filter(rtmi_builder_t* builder, const rtmi_build_box_t* boxes, uint64_t nboxes, const uint32_t* cand,
+                        uint64_t ncand, uint8_t* keep, uint64_t nkeep);
+int rtmi_builder_destroy(rtmi_builder_t* builder);
 
 /* Message of the last error on the calling thread ("" if none). */
 const char* rtmi_last_error(void);

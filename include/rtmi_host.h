@@ -55,6 +55,8 @@ void rth_populate_triangle_numbers(rth_scene_t* s);
 
 /* build_bounding_box / build_trivial_bounding_box into Scene.boxes */
 int rth_build_bounding_box(rth_scene_t* s, const float* orig3, float len2, uint64_t maxdepth, uint64_t minobjs, uint32_t threads);
+/* The same tree with every level's box/triangle overlap tests on the GPU (rtmi_builder_*); bit-equal to the host build. */
+int rth_build_bounding_box_gpu(rth_scene_t* s, const float* orig3, float len2, uint64_t maxdepth, uint64_t minobjs, int device);
 int rth_build_trivial_bounding_box(rth_scene_t* s, const float* orig3, float len2);
 int rth_box_contains_polygon(const rth_scene_t* s, const float* orig3, float len2, uint64_t tri);
 int rth_face_contains_triangle(const rth_scene_t* s, const float* p3, const float* norm3, float len2, uint64_t tri);

@@ -79,6 +79,8 @@ __device__ inline void tile_pixel(const DView& v, uint32_t lp, uint32_t& row, ui
     row = v.row0 + k * v.stripe_step + (lr - k * v.stripe_rows);
 }
 
+// which octree kernel tune.kernel == 0 selects (measured on MI355X)
+#define RTMI_DEFAULT_POOL 0
 #define RTMI_MAX_PASSES 32
 struct DCtrl {
     uint32_t count[RTMI_MAX_PASSES + 1];  // rays queued for pass k
@@ -333,7 +335,9 @@ __global__ void __launch_bounds__(256) k_trace(DScene sc, const float4* __restri
 
 }  // namespace rtmi
 #include "make_triangle.hpp"
+#include "build_octree.hpp"
 #include "trace_oct.hpp"
+#include "trace_pool.hpp"
 namespace rtmi {
 
 
@@ -721,6 +725,10 @@ struct rtmi_scene {
     std::string why_generic;   // reason when it did not
     int oct_blocks_per_cu = 8;
     size_t oct_lds = 0;
+    // k_trace_pool: rays per wave, slot stride (words), LDS bytes per wave, waves per CU; pool_P == 0: not available
+    uint32_t pool_P = 0, pool_stride = 0;
+    size_t pool_lds = 0;
+    int pool_blocks_per_cu = 0;
     // A tile is rendered as up to two interleaved sub-tiles, each with its own workspace on its own internal
     // stream, so that the small deep bounce passes of one overlap the bulk of the other.
     Work w[2];
@@ -915,6 +923,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     s->tune.refill_min0 = (uint32_t)std::min<size_t>(env_size("RTMI_REFILL_MIN0", 64), 64);
     s->tune.refill_min = (uint32_t)std::min<size_t>(env_size("RTMI_REFILL_MIN", 8), 64);
     s->tune.xcd_aware = (uint32_t)(env_size("RTMI_XCD_AWARE", 1) % 3);
+    s->tune.kernel = (uint32_t)std::min<size_t>(env_size("RTMI_KERNEL", 0), 2);
     s->verbose = getenv("RTMI_VERBOSE") != nullptr;
     s->trace_block = block;
     s->trace_lds = (size_t)levels * 16 * block;
@@ -956,6 +965,21 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
             int nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_oct<false, false>, 64, s->oct_lds) == hipSuccess && nb > 0)
                 s->oct_blocks_per_cu = nb;
+            // ray-pool form: 24 state words + 2 per stack level, an odd number of 16-B quads per slot (conflict-free
+            // ds_read_b128 of neighbouring slots); as many rays as fit 1/8 of the CU's 160 KB (8 waves per CU)
+            uint32_t quads = (24u + 2u * std::max<uint32_t>(1u, max_inner_depth) + 3u) / 4u;
+            if (!(quads & 1u)) quads++;
+            const uint32_t stride = quads * 4u;
+            const size_t budget = 160u * 1024u / 8u - 2u * RTMI_POOL_MAX;
+            const uint32_t P = (uint32_t)std::min<size_t>(RTMI_POOL_MAX, budget / (stride * 4u));
+            if (P >= 96u && hfn.size() / 4 < (1u << 22)) {
+                s->pool_P = P; s->pool_stride = stride;
+                s->pool_lds = (size_t)P * stride * 4u + 2u * RTMI_POOL_MAX;
+                nb = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_pool<false, false>, 64, s->pool_lds) == hipSuccess && nb > 0)
+                    s->pool_blocks_per_cu = nb;
+                else s->pool_P = 0;
+            }
         }
     }
     own.s = nullptr;
@@ -997,7 +1021,7 @@ int rtmi_scene_get_tuning(rtmi_scene_t* s, rtmi_tuning_t* out) {
 int rtmi_scene_set_tuning(rtmi_scene_t* s, const rtmi_tuning_t* in) {
     if (!s || !in) return fail(RTMI_ERR_INVALID, "NULL argument");
     if (in->batch_paths == 0 || in->streams < 1 || in->streams > 2 || in->oct_waves_per_cu > 32 || in->refill_min0 < 1 ||
-        in->refill_min0 > 64 || in->refill_min < 1 || in->refill_min > 64 || in->xcd_aware > 2)
+        in->refill_min0 > 64 || in->refill_min < 1 || in->refill_min > 64 || in->xcd_aware > 2 || in->kernel > 2)
         return fail(RTMI_ERR_INVALID, "tuning value out of range");
     s->tune = *in;
     return RTMI_OK;
@@ -1039,7 +1063,17 @@ static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* q
         const dim3 grid((unsigned)(s->num_cu * per_cu)), block(64);
         const int refill = (int)(pass == 0 ? s->tune.refill_min0 : s->tune.refill_min);
         const int xcd = (int)(s->tune.xcd_aware % 3u);  // 1 = ranges by XCC_ID, 2 = by blockIdx % 8, 0 = one range
-        if (s->options & RTMI_OPT_FAST)
+        const bool pool = s->pool_P != 0 && s->tune.kernel != 1u && (s->tune.kernel == 2u || RTMI_DEFAULT_POOL);
+        if (pool) {
+            const int ppc = s->tune.oct_waves_per_cu ? std::min<int>((int)s->tune.oct_waves_per_cu, s->pool_blocks_per_cu) : s->pool_blocks_per_cu;
+            const dim3 pgrid((unsigned)(s->num_cu * ppc));
+            if (s->options & RTMI_OPT_FAST)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_pool<COUNT, true>), pgrid, block, s->pool_lds, st, s->d, qo, qd, w.ctrl.p, pass,
+                                   w.hit_tf.p, w.hit_t.p, refill, xcd, s->pool_P, s->pool_stride);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_pool<COUNT, false>), pgrid, block, s->pool_lds, st, s->d, qo, qd, w.ctrl.p, pass,
+                                   w.hit_tf.p, w.hit_t.p, refill, xcd, s->pool_P, s->pool_stride);
+        } else if (s->options & RTMI_OPT_FAST)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT, true>), grid, block, s->oct_lds, st, s->d, qo, qd, w.ctrl.p, pass,
                                w.hit_tf.p, w.hit_t.p, refill, xcd);
         else
@@ -1409,6 +1443,88 @@ int rtmi_make_triangles(int device, const float* corners9_host, uint64_t n, cons
         memcpy(t.sides, o + 7, 36); memcpy(t.side_lens, o + 16, 12);
         out_host[i] = t;
     }
+    return RTMI_OK;
+    RTMI_GUARD_END
+}
+
+struct rtmi_builder {
+    int device = 0;
+    uint64_t ntris = 0;
+    int num_cu = 256;
+    DevBuf<float> tris;
+    DevBuf<float4> geo;
+    DevBuf<uint4> rng;
+    DevBuf<uint2> items;
+    DevBuf<uint32_t> cand;
+    DevBuf<uint8_t> keep;
+};
+
+int rtmi_builder_create(int device, const float* tris15, uint64_t ntris, rtmi_builder_t** out) {
+    if (!out) return fail(RTMI_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!tris15 || ntris == 0) return fail(RTMI_ERR_INVALID, "no triangles");
+    if (ntris >= (1ull << 30)) return fail(RTMI_ERR_UNSUPPORTED, "more than 2^30 triangles");
+    const int ndev = rtmi_device_count();
+    if (ndev <= 0) return fail(RTMI_ERR_NO_DEVICE, "no HIP device visible: the MI355X kernels cannot run (there is no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(RTMI_ERR_INVALID, "device index out of range");
+    RTMI_GUARD_BEGIN
+    HIPCHK(hipSetDevice(device));
+    rtmi_builder* b = new rtmi_builder();
+    b->device = device; b->ntris = ntris;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) b->num_cu = prop.multiProcessorCount;
+    hipError_t e = b->tris.ensure(ntris * 15);
+    if (e == hipSuccess) e = hipMemcpy(b->tris.p, tris15, ntris * 15 * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { rtmi_builder_destroy(b); return fail(hip_code(e), std::string("rtmi_builder_create: ") + hipGetErrorString(e)); }
+    *out = b;
+    return RTMI_OK;
+    RTMI_GUARD_END
+}
+
+int rtmi_builder_destroy(rtmi_builder_t* b) {
+    if (!b) return RTMI_OK;
+    (void)hipSetDevice(b->device);
+    b->tris.release(); b->geo.release(); b->rng.release(); b->items.release(); b->cand.release(); b->keep.release();
+    delete b;
+    return RTMI_OK;
+}
+
+int rtmi_builder_filter(rtmi_builder_t* b, const rtmi_build_box_t* boxes, uint64_t nboxes, const uint32_t* cand, uint64_t ncand,
+                        uint8_t* keep, uint64_t nkeep) {
+    if (!b) return fail(RTMI_ERR_INVALID, "builder is NULL");
+    if (nboxes == 0 || nkeep == 0) return RTMI_OK;
+    if (!boxes || !cand || !keep) return fail(RTMI_ERR_INVALID, "NULL argument");
+    if (nboxes >= (1ull << 32) || ncand >= (1ull << 32)) return fail(RTMI_ERR_UNSUPPORTED, "level too large for 32-bit indices");
+    RTMI_GUARD_BEGIN
+    // validate on the host: every range inside `cand` / `keep`, every candidate a triangle of the handle
+    for (uint64_t k = 0; k < ncand; k++)
+        if (cand[k] >= b->ntris) return fail(RTMI_ERR_INVALID, "candidate triangle index out of range");
+    std::vector<float4> geo(nboxes);
+    std::vector<uint4> rng(nboxes);
+    std::vector<uint2> items;
+    for (uint64_t i = 0; i < nboxes; i++) {
+        const rtmi_build_box_t& bx = boxes[i];
+        if ((uint64_t)bx.cand_first + bx.cand_count > ncand || bx.keep_first + bx.cand_count > nkeep)
+            return fail(RTMI_ERR_INVALID, "box candidate range out of bounds");
+        geo[i] = make_float4(bx.orig[0], bx.orig[1], bx.orig[2], bx.len2);
+        rng[i] = make_uint4(bx.cand_first, bx.cand_count, (uint32_t)bx.keep_first, (uint32_t)(bx.keep_first >> 32));
+        for (uint32_t lo = 0; lo < bx.cand_count; lo += 256) items.push_back(make_uint2((uint32_t)i, lo));
+    }
+    if (items.empty()) return RTMI_OK;
+    if (items.size() >= (1ull << 32)) return fail(RTMI_ERR_UNSUPPORTED, "level too large");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(b->geo.ensure(nboxes)); HIPCHK(b->rng.ensure(nboxes)); HIPCHK(b->items.ensure(items.size()));
+    HIPCHK(b->cand.ensure(ncand)); HIPCHK(b->keep.ensure(nkeep));
+    HIPCHK(hipMemcpy(b->geo.p, geo.data(), nboxes * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->rng.p, rng.data(), nboxes * sizeof(uint4), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->items.p, items.data(), items.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->cand.p, cand, ncand * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(b->keep.p, 0, nkeep));
+    const unsigned grid = (unsigned)std::min<uint64_t>(items.size(), (uint64_t)b->num_cu * 64);
+    hipLaunchKernelGGL(k_box_contains, dim3(grid), dim3(256), 0, nullptr, b->tris.p, b->geo.p, b->rng.p, b->items.p, (uint32_t)items.size(),
+                       b->cand.p, b->keep.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(keep, b->keep.p, nkeep, hipMemcpyDeviceToHost));
     return RTMI_OK;
     RTMI_GUARD_END
 }

@@ -71,7 +71,7 @@ __device__ inline float min3f(float a, float b, float c) {
 }
 
 template <bool COUNT, bool FAST>
-__global__ void __launch_bounds__(64, 6) k_trace_oct(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
+__global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
                                                   DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
                                                   float* __restrict__ hit_t, int refill_min, int xcd_aware) {
     extern __shared__ uint32_t lds[];

@@ -117,6 +117,12 @@ int rth_build_bounding_box(rth_scene_t* s, const float* orig3, float len2, uint6
         s->scene.touch();
     });
 }
+int rth_build_bounding_box_gpu(rth_scene_t* s, const float* orig3, float len2, uint64_t maxdepth, uint64_t minobjs, int device) {
+    return guarded([&] {
+        s->scene.boxes = build_bounding_box_gpu(s->scene.tris, v3(orig3), len2, (size_t)maxdepth, (size_t)minobjs, device);
+        s->scene.touch();
+    });
+}
 int rth_build_trivial_bounding_box(rth_scene_t* s, const float* orig3, float len2) {
     return guarded([&] {
         s->scene.boxes = build_trivial_bounding_box(s->scene.tris, v3(orig3), len2);

@@ -305,8 +305,42 @@ void parallel_for(size_t n, unsigned threads, F&& f) {
 }
 }  // namespace
 
+namespace {
+BoundingBox build_bounding_box_impl(const std::vector<Triangle>& tris, const Point& orig, float len2, size_t maxdepth,
+                                    size_t minobjs, unsigned threads, rtmi_builder_t* gpu);
+}
+
 BoundingBox build_bounding_box(const std::vector<Triangle>& tris, const Point& orig, float len2, size_t maxdepth,
                                size_t minobjs, unsigned threads) {
+    return build_bounding_box_impl(tris, orig, len2, maxdepth, minobjs, threads, nullptr);
+}
+
+// The same tree with the overlap tests of every level evaluated on the GPU (rtmi_builder_filter, k_box_contains):
+// the flags are bit-identical to box_contains_polygon() above, the list bookkeeping stays here.
+BoundingBox build_bounding_box_gpu(const std::vector<Triangle>& tris, const Point& orig, float len2, size_t maxdepth,
+                                   size_t minobjs, int device) {
+    std::vector<float> rec(tris.size() * 15);
+    for (size_t i = 0; i < tris.size(); i++) {
+        float* o = rec.data() + i * 15;
+        memcpy(o, tris[i].incenter.v, 12); memcpy(o + 3, tris[i].norm.v, 12);
+        for (int k = 0; k < 3; k++) memcpy(o + 6 + 3 * k, tris[i].corners[k].v, 12);
+    }
+    rtmi_builder_t* b = nullptr;
+    if (rtmi_builder_create(device, rec.data(), tris.size(), &b) != RTMI_OK)
+        throw std::runtime_error(std::string("rtmi_builder_create: ") + rtmi_last_error());
+    try {
+        BoundingBox bb = build_bounding_box_impl(tris, orig, len2, maxdepth, minobjs, 1, b);
+        rtmi_builder_destroy(b);
+        return bb;
+    } catch (...) {
+        rtmi_builder_destroy(b);
+        throw;
+    }
+}
+
+namespace {
+BoundingBox build_bounding_box_impl(const std::vector<Triangle>& tris, const Point& orig, float len2, size_t maxdepth,
+                                    size_t minobjs, unsigned threads, rtmi_builder_t* gpu) {
     if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
     if (tris.size() >= (1ull << 30)) throw std::runtime_error("build_bounding_box: too many triangles");
     std::vector<std::vector<Tmp>> levels;
@@ -329,6 +363,35 @@ BoundingBox build_bounding_box(const std::vector<Triangle>& tris, const Point& o
             for (size_t lo = 0; lo < cand.size(); lo += CH)
                 items.push_back(Item{(uint32_t)b, (uint32_t)lo, (uint32_t)std::min(cand.size(), lo + CH)});
         }
+        if (gpu) {
+            // one device pass per level: the candidate lists (one per PARENT: its 8 children share it) are concatenated,
+            // every box names its parent's range, the flags come back in box order
+            std::vector<uint32_t> cand_flat;
+            std::vector<uint64_t> first_of_parent(d == 0 ? 1 : levels[d - 1].size(), UINT64_MAX);
+            std::vector<rtmi_build_box_t> bxs(cur.size());
+            uint64_t nkeep = 0;
+            for (size_t b = 0; b < cur.size(); b++) {
+                const size_t par = d == 0 ? 0 : (size_t)cur[b].parent;
+                const std::vector<uint32_t>& cand = (d == 0) ? all : levels[d - 1][par].objs;
+                if (first_of_parent[par] == UINT64_MAX) {
+                    first_of_parent[par] = cand_flat.size();
+                    cand_flat.insert(cand_flat.end(), cand.begin(), cand.end());
+                }
+                if (cand_flat.size() >= (1ull << 32)) throw std::runtime_error("build_bounding_box_gpu: level above 2^32 candidates");
+                rtmi_build_box_t& r = bxs[b];
+                for (int k = 0; k < 3; k++) r.orig[k] = cur[b].orig.v[k];
+                r.len2 = cur[b].len2;
+                r.cand_first = (uint32_t)first_of_parent[par];
+                r.cand_count = (uint32_t)cand.size();
+                r.keep_first = nkeep;
+                nkeep += cand.size();
+            }
+            std::vector<uint8_t> flat(nkeep);
+            if (rtmi_builder_filter(gpu, bxs.data(), bxs.size(), cand_flat.data(), cand_flat.size(), flat.data(), nkeep) != RTMI_OK)
+                throw std::runtime_error(std::string("rtmi_builder_filter: ") + rtmi_last_error());
+            for (size_t b = 0; b < cur.size(); b++)
+                memcpy(keep[b].data(), flat.data() + bxs[b].keep_first, keep[b].size());
+        } else
         parallel_for(items.size(), threads, [&](size_t k) {
             const Item& it = items[k];
             const Tmp& bx = cur[it.box];
@@ -405,6 +468,7 @@ BoundingBox build_bounding_box(const std::vector<Triangle>& tris, const Point& o
     }
     return out;
 }
+}  // namespace
 
 // ------------------------------------------------------------------ camera
 float to_radians(float deg) { return deg * (kPi / 180.0f); }
@@ -510,6 +574,7 @@ void HipRayCaster::apply_settings() {
     if (tuning_.refill_min0) t.refill_min0 = tuning_.refill_min0;
     if (tuning_.refill_min) t.refill_min = tuning_.refill_min;
     if (tuning_.xcd_aware) t.xcd_aware = tuning_.xcd_aware - 1;
+    if (tuning_.kernel) t.kernel = tuning_.kernel;
     if (rtmi_scene_set_tuning(handle_, &t) != RTMI_OK) throw std::runtime_error(std::string("rtmi_scene_set_tuning: ") + rtmi_last_error());
 }
 

@@ -98,6 +98,9 @@ bool face_contains_triangle(const Point& p, const Vec3& norm, float len2, const 
 BoundingBox build_empty_box();                                                                       // :781-788
 BoundingBox build_bounding_box(const std::vector<Triangle>& tris, const Point& orig, float len2,
                                size_t maxdepth, size_t minobjs, unsigned threads = 0);               // :790-845
+// The same tree, the box/triangle overlap tests of every level evaluated on the GPU (rtmi_builder_*); bit-equal result.
+BoundingBox build_bounding_box_gpu(const std::vector<Triangle>& tris, const Point& orig, float len2, size_t maxdepth,
+                                   size_t minobjs, int device = 0);
 BoundingBox build_trivial_bounding_box(const std::vector<Triangle>& tris, const Point& orig, float len2);  // :847-856
 
 // raytrace.rs:1297-1303 (debug_ctx / debug_en: out of scope)

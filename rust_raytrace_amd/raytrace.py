@@ -135,9 +135,13 @@ class Scene:
         _ffi.lib().rth_populate_triangle_numbers(self.h)
 
     # --- Scene.boxes
-    def build_bounding_box(self, orig, len2, maxdepth, minobjs, threads=0):
-        """raytrace.rs:790-845"""
-        _chk(_ffi.lib().rth_build_bounding_box(self.h, _p(_f(orig)), len2, maxdepth, minobjs, threads))
+    def build_bounding_box(self, orig, len2, maxdepth, minobjs, threads=0, gpu_device=None):
+        """raytrace.rs:790-845.  gpu_device: evaluate the box/triangle overlap tests of every level on that GPU
+        (rtmi_builder_*, k_box_contains) instead of on `threads` host threads; the tree is bit-equal either way."""
+        if gpu_device is not None:
+            _chk(_ffi.lib().rth_build_bounding_box_gpu(self.h, _p(_f(orig)), len2, maxdepth, minobjs, int(gpu_device)))
+        else:
+            _chk(_ffi.lib().rth_build_bounding_box(self.h, _p(_f(orig)), len2, maxdepth, minobjs, threads))
 
     def build_trivial_bounding_box(self, orig, len2):
         """raytrace.rs:847-856"""
@@ -305,7 +309,7 @@ def quantize(rgba):
 
 
 # ---------------------------------------------------------------- scenes of the benchmark configs
-def canonical_scene(obj_path, accel="octree", maxdepth=10, minobjs=19, teapot_surface=None, threads=0):
+def canonical_scene(obj_path, accel="octree", maxdepth=10, minobjs=19, teapot_surface=None, threads=0, gpu_build=None):
     """The scene of raytrace/src/main.rs:116-164."""
     s = Scene(with_dummy=True)
     tsurf = teapot_surface or SurfaceKind.Matte(make_color(252, 119, 0), 0.2)
@@ -317,13 +321,13 @@ def canonical_scene(obj_path, accel="octree", maxdepth=10, minobjs=19, teapot_su
                        SurfaceKind.Reflective(0.002, make_color(230, 230, 230), 0.7), side, -1.0)
     s.populate_triangle_numbers()
     if accel == "octree":
-        s.build_bounding_box([0.0, 0.0, 20.1], 20.0, maxdepth, minobjs, threads)
+        s.build_bounding_box([0.0, 0.0, 20.1], 20.0, maxdepth, minobjs, threads, gpu_device=gpu_build)
     elif accel == "trivial":
         s.build_trivial_bounding_box([0.0, 0.0, 0.0], 20.0)
     return s
 
 
-def grid_scene(obj_path, maxdepth=10, minobjs=19, n=8, threads=0):
+def grid_scene(obj_path, maxdepth=10, minobjs=19, n=8, threads=0, gpu_build=None):
     """BASELINE config 5: n instances of teapot_tri.obj on a 2x2x2 grid (spacing 9 units) inside the canonical
     root box — the octree-traversal stress scene (8 x 6320 + 1 = 50 561 triangles)."""
     s = Scene(with_dummy=True)
@@ -340,7 +344,7 @@ def grid_scene(obj_path, maxdepth=10, minobjs=19, n=8, threads=0):
                                    surfs[k % 4], 0.05 if k % 2 == 0 else 0.0)
                 k += 1
     s.populate_triangle_numbers()
-    s.build_bounding_box([0.0, 0.0, 20.1], 20.0, maxdepth, minobjs, threads)
+    s.build_bounding_box([0.0, 0.0, 20.1], 20.0, maxdepth, minobjs, threads, gpu_device=gpu_build)
     return s
 
 

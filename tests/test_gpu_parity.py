@@ -645,3 +645,61 @@ def test_caster_multi_device_fanout_in_library(canonical_pair):
     assert_bits_equal(ref, one, "single device again")
     with pytest.raises(RuntimeError):
         R.HipRayCaster(seed=12, devices=[0, 99]).walk_rays(vp, sp, img, 1, False)
+
+
+@pytest.mark.parametrize("which", ["canonical", "grid"])
+def test_octree_build_on_gpu_equals_host_build(which):
+    """f2: build_bounding_box (raytrace.rs:790-845) with every level's box_contains_polygon tests (raytrace.rs:753-779) on
+    the GPU (rtmi_builder_filter / k_box_contains).  The flattened tree -- box geometry, topology, leaf lists -- equals the
+    host builder's bit for bit at the stated octree (10, 19), for the canonical scene and the 8-teapot grid (config 5);
+    the host builder equals the oracle's (tests/test_host_cpu.py)."""
+    import os
+    import time
+    from conftest import TEAPOT_TRI
+    R = _R()
+    threads = max(1, len(os.sched_getaffinity(0)))
+    mk = R.canonical_scene if which == "canonical" else R.grid_scene
+    t0 = time.time()
+    host = mk(TEAPOT_TRI, threads=threads)
+    t1 = time.time()
+    gpu = mk(TEAPOT_TRI, gpu_build=0)
+    t2 = time.time()
+    gh, th, rh = host.tree()
+    gg, tg, rg = gpu.tree()
+    assert gh.shape == gg.shape and th.shape == tg.shape and rh.shape == rg.shape
+    assert_bits_equal(gh, gg, "box geometry")
+    assert np.array_equal(th, tg), "topology"
+    assert np.array_equal(rh, rg), "leaf lists"
+    print(f"[{which}] host build ({threads} threads) {t1 - t0:.2f} s, GPU build {t2 - t1:.2f} s (includes OBJ load + make_triangle), "
+          f"{len(gh)} boxes, {len(rh)} references")
+    # a frame from the GPU-built tree is the frame from the host-built tree
+    vp = R.canonical_viewport(48, 48, 5, 2)
+    a = np.zeros((48, 48, 4), np.float32)
+    b = np.zeros_like(a)
+    R.HipRayCaster(seed=3).walk_rays(vp, host, a, 1, False)
+    R.HipRayCaster(seed=3).walk_rays(vp, gpu, b, 1, False)
+    assert_bits_equal(a, b, "frames")
+
+
+def test_pool_kernel_is_bit_exact(canonical_pair):
+    """tuning kernel=2 selects k_trace_pool (per-wave ray pool in LDS, free ray-to-lane assignment each step); measured
+    slower than the default on MI355X and therefore opt-in, but it stays exact: image bits and all six work
+    counters against the oracle, plus edge-case rays."""
+    so, sp = canonical_pair
+    orc, R = _orc(), _R()
+    w, h, spp = 48, 40, 3
+    vo = orc.canonical_viewport(w, h)
+    vp = R.canonical_viewport(w, h, 5, spp)
+    ref, cn = so.render(w, h, vo, 5, spp, seed=5, threads=8)
+    img = np.zeros((h, w, 4), np.float32)
+    ctx = R.HipRayCaster(seed=5, options=R.OPT_COUNTERS, tuning={"kernel": 2}).walk_rays(vp, sp, img, 1, False)
+    assert_bits_equal(ref, img, "pool kernel image")
+    for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
+        assert ctx.stats[k] == cn[k], k
+    pair = build_pair(recipe_axis_box())
+    vo = orc.create_viewport(33, 33, (1.0, 1.0), [0.0, 0.0, 0.0], orc.unit([0.0, 0.0, 1.0]), 90.0, 0.0)
+    vp = R.create_viewport((33, 33), (1.0, 1.0), [0.0, 0.0, 0.0], R.unit([0.0, 0.0, 1.0]), 90.0, 0.0, 5, 1)
+    ref, _ = pair[0].render(33, 33, vo, 5, 1)
+    img = np.zeros((33, 33, 4), np.float32)
+    R.HipRayCaster(tuning={"kernel": 2}).walk_rays(vp, pair[1], img, 1, False)
+    assert_bits_equal(ref, img, "pool kernel, axis-aligned scene")
