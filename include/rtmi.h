@@ -81,7 +81,7 @@ typedef struct rtmi_stats {
     double kernel_ms;  /* device time span of the call (HIP events on the caller's stream)               */
     double trace_ms;   /* sum of the durations of the closest-hit launches (HIP events on their streams)  */
     uint32_t trace_launches;
-    uint32_t streams;  /* internal streams that ran concurrently (1 or 2): launches overlap when 2        */
+    uint32_t streams;  /* internal streams that ran concurrently (1..4): launches overlap when > 1       */
 } rtmi_stats_t;
 
 /* A set of image rows: `nrows` rows taken in stripes of `stripe_rows`
@@ -126,7 +126,7 @@ int rtmi_scene_set_options(rtmi_scene_t* scene, uint32_t options);
  * here.  None of them changes a pixel: any batch size, stream count or stripe split gives the same image. */
 typedef struct rtmi_tuning {
     uint64_t batch_paths;       /* paths (pixel samples) per batch of the wavefront pipeline; default 256 Mi  */
-    uint32_t streams;           /* 1 or 2 internal HIP streams (interleaved sub-tiles); default 2             */
+    uint32_t streams;           /* 1..4 internal HIP streams (interleaved sub-tiles of a tile); default 2        */
     uint32_t subtile_min_paths; /* tiles with fewer paths are not split over two streams; default 32768       */
     uint32_t oct_waves_per_cu;  /* persistent waves per CU of the octree kernel; 0 = occupancy query          */
     uint32_t refill_min0;       /* idle lanes before a wave refills, primary pass (64 = whole wave); default 64 */

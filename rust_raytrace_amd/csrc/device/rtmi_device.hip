@@ -82,6 +82,7 @@ __device__ inline void tile_pixel(const DView& v, uint32_t lp, uint32_t& row, ui
 // which octree kernel tune.kernel == 0 selects (measured on MI355X)
 #define RTMI_DEFAULT_POOL 0
 #define RTMI_MAX_PASSES 32
+#define RTMI_MAX_STREAMS 4  // interleaved sub-tiles of one tile, each on its own internal stream
 struct DCtrl {
     uint32_t count[RTMI_MAX_PASSES + 1];  // rays queued for pass k
     uint32_t head[RTMI_MAX_PASSES + 1];   // work-fetch cursor of pass k
@@ -731,9 +732,9 @@ struct rtmi_scene {
     int pool_blocks_per_cu = 0;
     // A tile is rendered as up to two interleaved sub-tiles, each with its own workspace on its own internal
     // stream, so that the small deep bounce passes of one overlap the bulk of the other.
-    Work w[2];
-    hipStream_t istream[2] = {nullptr, nullptr};
-    hipEvent_t fork_ev = nullptr, end_ev = nullptr, join_ev[2] = {nullptr, nullptr};
+    Work w[RTMI_MAX_STREAMS];
+    hipStream_t istream[RTMI_MAX_STREAMS] = {};
+    hipEvent_t fork_ev = nullptr, end_ev = nullptr, join_ev[RTMI_MAX_STREAMS] = {};
     DevBuf<float4> tile;
     DevBuf<uint8_t> qbytes;
     DevBuf<uint8_t> mstage, mframe;  // rtmi_render_frame_multi, root scene: received bands / the frame
@@ -745,7 +746,7 @@ struct rtmi_scene {
     // against setenv): waves per CU of the octree kernel, refill thresholds, XCD mode, streams, batch size
     rtmi_tuning_t tune{};
     bool verbose = false;
-    unsigned long long vprev[2][13] = {};  // verbose per-pass deltas (per handle: no shared statics)
+    unsigned long long vprev[RTMI_MAX_STREAMS][13] = {};  // verbose per-pass deltas (per handle: no shared statics)
 };
 
 static size_t env_size(const char* name, size_t dflt) {
@@ -917,7 +918,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     rtmi_scene* s = own.s;
     s->device = device;
     s->tune.batch_paths = env_size("RTMI_BATCH_PATHS", (size_t)256 << 20);
-    s->tune.streams = (uint32_t)std::min<size_t>(env_size("RTMI_STREAMS", 2), 2);
+    s->tune.streams = (uint32_t)std::min<size_t>(env_size("RTMI_STREAMS", 2), RTMI_MAX_STREAMS);
     s->tune.subtile_min_paths = (uint32_t)std::min<size_t>(env_size("RTMI_SUBTILE_MIN_PATHS", 32768), 0xFFFFFFFFu);
     s->tune.oct_waves_per_cu = (uint32_t)std::min<size_t>(env_size("RTMI_OCT_WAVES_PER_CU", 0), 32);
     s->tune.refill_min0 = (uint32_t)std::min<size_t>(env_size("RTMI_REFILL_MIN0", 64), 64);
@@ -945,7 +946,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     s->why_generic = why;
     if (e == hipSuccess && s->octree) e = up(s->fnodes, hfn);
     if (e == hipSuccess && s->octree) e = up(s->oblocks, hob);
-    for (int k = 0; k < 2 && e == hipSuccess; k++) {
+    for (int k = 0; k < RTMI_MAX_STREAMS && e == hipSuccess; k++) {
         e = s->w[k].ctrl.ensure(1);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->istream[k], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreate(&s->w[k].ev[0]);
@@ -993,7 +994,7 @@ int rtmi_scene_destroy(rtmi_scene_t* s) {
     (void)hipSetDevice(s->device);
     s->nodes.release(); s->refs.release(); s->tplane.release(); s->tedge.release(); s->mats.release();
     s->fnodes.release(); s->oblocks.release();
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < RTMI_MAX_STREAMS; k++) {
         s->w[k].release();
         if (s->istream[k]) (void)hipStreamDestroy(s->istream[k]);
         if (s->join_ev[k]) (void)hipEventDestroy(s->join_ev[k]);
@@ -1020,7 +1021,7 @@ int rtmi_scene_get_tuning(rtmi_scene_t* s, rtmi_tuning_t* out) {
 
 int rtmi_scene_set_tuning(rtmi_scene_t* s, const rtmi_tuning_t* in) {
     if (!s || !in) return fail(RTMI_ERR_INVALID, "NULL argument");
-    if (in->batch_paths == 0 || in->streams < 1 || in->streams > 2 || in->oct_waves_per_cu > 32 || in->refill_min0 < 1 ||
+    if (in->batch_paths == 0 || in->streams < 1 || in->streams > RTMI_MAX_STREAMS || in->oct_waves_per_cu > 32 || in->refill_min0 < 1 ||
         in->refill_min0 > 64 || in->refill_min < 1 || in->refill_min > 64 || in->xcd_aware > 2 || in->kernel > 2)
         return fail(RTMI_ERR_INVALID, "tuning value out of range");
     s->tune = *in;
@@ -1152,9 +1153,10 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
         step = S;
     }
     const uint32_t nstripes = (nrows + S - 1) / S;
-    uint32_t nsub = std::min<uint32_t>(std::max<uint32_t>(s->tune.streams, 1u), 2u);
-    if (nstripes < 2 || npix * spp < s->tune.subtile_min_paths) nsub = 1;
-    SubTile sub[2];
+    uint32_t nsub = std::min<uint32_t>(std::max<uint32_t>(s->tune.streams, 1u), (uint32_t)RTMI_MAX_STREAMS);
+    nsub = std::min<uint32_t>(nsub, nstripes);
+    if (npix * spp < s->tune.subtile_min_paths) nsub = 1;
+    SubTile sub[RTMI_MAX_STREAMS];
     for (uint32_t t = 0; t < nsub; t++) {
         DView& dv = sub[t].dv;
         dv.orig = mk(vp->orig[0], vp->orig[1], vp->orig[2]);
@@ -1172,7 +1174,9 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     // batch = whole pixels with all their samples
     const size_t want_paths = (size_t)std::max<uint64_t>(s->tune.batch_paths, 1) / nsub;
     uint64_t pix_per_batch = std::max<uint64_t>(1, want_paths / spp);
-    pix_per_batch = std::min<uint64_t>(pix_per_batch, std::max(sub[0].npix, sub[nsub - 1].npix));
+    uint64_t max_sub_npix = 0;
+    for (uint32_t t = 0; t < nsub; t++) max_sub_npix = std::max(max_sub_npix, sub[t].npix);
+    pix_per_batch = std::min<uint64_t>(pix_per_batch, max_sub_npix);
     if (pix_per_batch * spp >= (1ull << 31)) return fail(RTMI_ERR_UNSUPPORTED, "batch above 2^31 paths");
     for (uint32_t t = 0; t < nsub; t++) {
         int rc = ensure_workspace(s->w[t], (size_t)(std::min<uint64_t>(pix_per_batch, sub[t].npix) * spp), maxdepth);
@@ -1188,7 +1192,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     HIPCHK(hipEventRecord(s->fork_ev, ust));
     for (uint32_t t = 0; t < nsub; t++) HIPCHK(hipStreamWaitEvent(s->istream[t], s->fork_ev, 0));
 
-    const uint64_t max_npix = std::max(sub[0].npix, sub[nsub - 1].npix);
+    const uint64_t max_npix = max_sub_npix;
     for (uint64_t p0 = 0; p0 < max_npix; p0 += pix_per_batch) {
         // enqueue this batch of every sub-tile (no host dependency inside a batch: queue sizes live on the device)
         for (uint32_t t = 0; t < nsub; t++) {
@@ -1400,7 +1404,7 @@ int rtmi_debug_counters(rtmi_scene_t* s, unsigned long long* out16) {
     if (!s || !out16) return fail(RTMI_ERR_INVALID, "NULL argument");
     HIPCHK(hipSetDevice(s->device));
     memset(out16, 0, 16 * sizeof(unsigned long long));
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < RTMI_MAX_STREAMS; k++) {
         DCtrl h;
         HIPCHK(hipMemcpy(&h, s->w[k].ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost));
         for (int j = 0; j < 16; j++) out16[j] += h.dbg[j];

@@ -22,10 +22,11 @@ lib.rth_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
 out = (C.c_ulonglong * 16)()
 lib.rth_debug_counters(scene.h, out)
 d = list(out)
-names = ["S steps", "S lanes", "L steps", "L lanes", "refills", "refill lanes", "edge blocks", "edge lanes"]
+names = ["S steps", "S lanes", "L steps", "L lanes", "refills", "refill lanes", "edge blocks", "edge lanes", "scan steps", "scan lanes"]
 for n, v in zip(names, d):
     print(f"{n:14s} {v}")
 rays = ctx.stats["rays"]
 print("NOTE: dbg counters cover only the LAST batch/pass sequence of the call (ctrl is reset per batch)")
 print(f"S lane util {d[1] / max(d[0] * 64, 1):.3f}   L lane util {d[3] / max(d[2] * 64, 1):.3f}   edge lanes/block {d[7] / max(d[6], 1):.2f}")
-print(f"per ray: S steps {d[1] / rays:.1f}  L steps {d[3] / rays:.1f}  wave-steps per ray-wave {(d[0] + d[2]) * 64 / rays:.1f}")
+print(f"per ray: S steps {d[1] / rays:.1f}  L (test) steps {d[3] / rays:.1f}  scan steps {d[9] / rays:.1f}  wave-steps per ray-wave: S {d[0] * 64 / rays:.1f} test {d[2] * 64 / rays:.1f} scan {d[8] * 64 / rays:.1f}")
+print(f"scan lane util {d[9] / max(d[8] * 64, 1):.3f}   tri tests {ctx.stats['tri_tests'] / rays:.1f} per ray, tested after memo {4 * d[3] / rays:.1f} slots per ray")
