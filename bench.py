@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--check", action="store_true", help="rank 0 verifies the gathered frame against a single-tile render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
+    ap.add_argument("--no-d2h-leg", action="store_true", help="skip the extra timed loop that includes the frame's device-to-host copy")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
     preset = CONFIGS[args.config]
@@ -213,7 +214,7 @@ def main():
     cpu_baseline = None
     incl_d2h = None
     if rank == 0:
-        if world == 1:
+        if world == 1 and not args.no_d2h_leg:
             # ---- frame device-to-host copy inside the window (SURVEY 8d's GPU window); never the headline `value`
             host = torch.empty(frame.shape, dtype=frame.dtype, pin_memory=True)
             n2 = min(args.steps, 3)
@@ -284,11 +285,20 @@ def roofline_object(args, caster, scene, vp, tile, local, stream, rays_per_frame
     n_box, n_tri, n_full = st["box_tests"], st["tri_tests"], st["full_tests"]
     flops = 15 * n_box + 28 * n_tri + 21 * n_full           # per frame (SURVEY 8d "algorithmic flops per unit")
     alg_bytes = 16 * n_box + (4 + 28) * n_tri + 52 * n_full  # per frame (SURVEY 8d "algorithmic bytes per unit")
-    n_launch_frame = max(st["trace_launches"], 1)
-    avg_launch_ms = trace_ms / max(launches, 1)                # HIP events on the launch streams, timed region
-    frame_ms = kernel_ms / args.steps                          # device time span of one frame (both streams)
-    achieved = flops / n_launch_frame / (avg_launch_ms * 1e-3) / 1e12
+    frame_ms = kernel_ms / args.steps                          # device time span of one frame in the timed region
     chip = flops / (frame_ms * 1e-3) / 1e12
+    # Per-launch duration of the dominant kernel, measured live with HIP events on its launch stream.  In the timed
+    # region two sub-tiles run on two streams and their launches share the GPU, which stretches every launch; so the
+    # kernel is also run ALONE here: one frame on a single internal stream (tuning streams = 1), one launch per pass.
+    from rust_raytrace_amd import raytrace as R2
+    solo = R2.HipRayCaster(seed=caster.seed, device=caster.device, options=base_opts, tuning={"streams": 1})
+    solo.walk_tile_device(vp, scene, tile, local.data_ptr(), stream.cuda_stream)
+    sctx = solo.walk_tile_device(vp, scene, tile, local.data_ptr(), stream.cuda_stream)
+    n_launch_frame = max(sctx.stats["trace_launches"], 1)
+    avg_launch_ms = sctx.stats["trace_ms"] / n_launch_frame
+    solo_frame_ms = sctx.stats["kernel_ms"]
+    achieved = flops / n_launch_frame / (avg_launch_ms * 1e-3) / 1e12
+    shared_launch_ms = trace_ms / max(launches, 1)             # the same per launch in the timed region (two streams)
     # measured fabric traffic and VALU issue rate: from the committed rocprofv3 --pmc passes of this config (a profile
     # is a separate run: rocprofv3 cannot run inside bench.py); null when the workload is not the profiled one
     prof = None
@@ -309,7 +319,9 @@ def roofline_object(args, caster, scene, vp, tile, local, stream, rays_per_frame
         "traffic": traffic,
         "raw": {"rays": st["rays"], "box_tests": n_box, "tri_tests": n_tri, "full_tests": n_full, "nodes": st["nodes"],
                 "leaves": st["leaves"], "trace_launches_per_frame": n_launch_frame, "avg_launch_ms": round(avg_launch_ms, 3),
-                "frame_device_ms": round(frame_ms, 3), "streams": int(st.get("streams", 1))},
+                "single_stream_frame_device_ms": round(solo_frame_ms, 3),
+                "timed_region": {"frame_device_ms": round(frame_ms, 3), "streams": int(st.get("streams", 1)),
+                                 "launches_per_frame": int(launches / args.steps), "avg_launch_ms_sharing_the_gpu": round(shared_launch_ms, 3)}},
         "per_ray": {"box_tests": round(n_box / max(st["rays"], 1), 1), "tri_tests": round(n_tri / max(st["rays"], 1), 1),
                     "full_tests": round(n_full / max(st["rays"], 1), 2), "flops": round(flops / max(st["rays"], 1)),
                     "algorithmic_bytes": round(alg_bytes / max(st["rays"], 1))},
@@ -331,9 +343,11 @@ def roofline_object(args, caster, scene, vp, tile, local, stream, rays_per_frame
                                          "note": "counters from the committed profile of this workload (profiles/pmc_latest.json), "
                                                  "rates against THIS run's frame time"} if same_cfg else None),
         },
-        "note": "achieved = algorithmic FP32 flops of ONE closest-hit launch (device counters of a counting pass / launches) / its "
-                "HIP-event duration in the timed region; peak = 157.3/2 TFLOP/s because a*b+c may not be contracted (bit parity). "
-                "Two sub-tiles run on two streams, so launches overlap: chip_frame prices a frame's flops against the frame's device time.",
+        "note": "achieved = algorithmic FP32 flops of ONE closest-hit launch (device counters of a counting pass / launches per frame) / "
+                "its average HIP-event duration with the kernel alone on the GPU (one internal stream; this is what rocprofv3 "
+                "--kernel-trace of RTMI_STREAMS=1 reports, profiles/); peak = 157.3/2 TFLOP/s because a*b+c may not be contracted "
+                "(bit parity).  The timed region runs two sub-tiles on two streams whose launches overlap: chip_frame prices a frame's "
+                "flops against the frame's device time there.",
     }
 
 

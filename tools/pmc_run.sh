@@ -12,6 +12,6 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_W
            "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $out/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-counters "$@" > $out/p$i.log 2>&1 || echo "pass $i failed: $(tail -2 $out/p$i.log)"
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $out/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-counters --no-d2h-leg "$@" > $out/p$i.log 2>&1 || echo "pass $i failed: $(tail -2 $out/p$i.log)"
 done
 python3 $GRAFT_REPO_ROOT/tools/pmc_summarize.py $out ${RTMI_PMC_CONFIG:+"$RTMI_PMC_CONFIG"}
