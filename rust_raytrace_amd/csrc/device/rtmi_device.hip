@@ -61,9 +61,11 @@ struct DScene {
     // exact-octree form (trace_oct.hpp); null when the tree is not an exact octree
     const uint4* fnodes;
     const uint4* oblocks;
+    const uint32_t* wlinks;  // 8 explicit first-block indices per FN_WIDE box
     float root_half;
     uint32_t olevels;
 };
+#define RTMI_FN_WIDE 0x10000u
 
 struct DView {
     V4 orig, cam, vu, vv;
@@ -721,6 +723,7 @@ struct rtmi_scene {
     DevBuf<uint32_t> refs;
     DevBuf<float4> tplane, tedge, mats;
     DevBuf<uint4> fnodes, oblocks;
+    DevBuf<uint32_t> wlinks;
     bool root_is_leaf = false; // build_trivial_bounding_box: one list for every ray -> k_trace_linear
     bool octree = false;       // the tree passed the exact-octree check
     std::string why_generic;   // reason when it did not
@@ -816,6 +819,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     //      Inner boxes get a 64-B record (centre, child mask, 8 child links); leaves only their reference blocks.
     std::vector<uint4> hfn;
     std::vector<uint4> hob;
+    std::vector<uint32_t> hwl;  // explicit block indices of FN_WIDE boxes
     std::string why;
     {
         auto fb = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
@@ -848,12 +852,14 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
             }
         }
         if (ok) {
-            hfn.assign(4 * ninner, make_uint4(0, 0, 0, 0));
+            hfn.assign(2 * ninner, make_uint4(0, 0, 0, 0));
             for (uint64_t i = 0; i < nboxes && ok; i++) {
                 const rtmi_box_t& b = boxes[i];
                 if (b.is_leaf) continue;
                 const float h = b.len2 / 2.f;
-                uint32_t mask = 0, link[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                uint32_t mask = 0, leafmask = 0, first_block[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                uint32_t base_inner = 0, base_block = 0;
+                bool have_inner = false, have_leaf = false;
                 int prev = -1;
                 for (uint32_t k = 0; k < b.count && ok; k++) {
                     const rtmi_box_t& c = boxes[b.first + k];
@@ -867,15 +873,34 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
                     if (ok && oct <= prev) { ok = false; why = "children are not in octant order"; }
                     prev = oct;
                     mask |= 1u << oct;
-                    link[oct & 7] = slot[b.first + k];  // an inner child is never record 0 (that is the root)
+                    // children follow each other in box order, so the inner ones have consecutive records and the leaf
+                    // ones consecutive runs of blocks: one base each + (leaves) a byte offset per octant
+                    if (c.is_leaf) {
+                        leafmask |= 1u << oct;
+                        first_block[oct & 7] = slot[b.first + k] & 0x7FFFFFFFu;
+                        if (!have_leaf) { base_block = first_block[oct & 7]; have_leaf = true; }
+                    } else if (!have_inner) { base_inner = slot[b.first + k]; have_inner = true; }
                 }
-                uint4* rec = &hfn[4 * (size_t)slot[i]];
-                rec[0] = make_uint4(fb(b.orig[0]), fb(b.orig[1]), fb(b.orig[2]), mask);
-                rec[1] = make_uint4(link[0], link[1], link[2], link[3]);
-                rec[2] = make_uint4(link[4], link[5], link[6], link[7]);
+                uint32_t w = mask | (leafmask << 8), offlo = 0, offhi = 0, q1y = base_block;
+                bool wide = false;
+                for (int o = 0; o < 8; o++)
+                    if ((leafmask >> o) & 1u) wide |= first_block[o] - base_block > 255u;
+                if (wide) {
+                    w |= RTMI_FN_WIDE;
+                    q1y = (uint32_t)(hwl.size() / 8);
+                    hwl.insert(hwl.end(), first_block, first_block + 8);
+                } else {
+                    for (int o = 0; o < 8; o++) {
+                        const uint32_t off = ((leafmask >> o) & 1u) ? first_block[o] - base_block : 0u;
+                        if (o < 4) offlo |= off << (8 * o); else offhi |= off << (8 * (o - 4));
+                    }
+                }
+                uint4* rec = &hfn[2 * (size_t)slot[i]];
+                rec[0] = make_uint4(fb(b.orig[0]), fb(b.orig[1]), fb(b.orig[2]), w);
+                rec[1] = make_uint4(base_inner, q1y, offlo, offhi);
             }
         }
-        if (!ok) { hfn.clear(); hob.clear(); }
+        if (!ok) { hfn.clear(); hob.clear(); hwl.clear(); }
     }
 
     std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t>, uint32_t> matmap;
@@ -946,6 +971,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     s->why_generic = why;
     if (e == hipSuccess && s->octree) e = up(s->fnodes, hfn);
     if (e == hipSuccess && s->octree) e = up(s->oblocks, hob);
+    if (e == hipSuccess && s->octree) e = up(s->wlinks, hwl);
     for (int k = 0; k < RTMI_MAX_STREAMS && e == hipSuccess; k++) {
         e = s->w[k].ctrl.ensure(1);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->istream[k], hipStreamNonBlocking);
@@ -958,7 +984,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     if (e != hipSuccess) return fail(hip_code(e), std::string("scene upload: ") + hipGetErrorString(e));
     s->d = DScene{s->nodes.p, s->refs.p, s->tplane.p, s->tedge.p, s->mats.p,
                   (uint32_t)nboxes, (uint32_t)ntris, (uint32_t)matmap.size(), levels,
-                  s->octree ? s->fnodes.p : nullptr, s->octree ? s->oblocks.p : nullptr, boxes[0].len2, max_inner_depth + 1};
+                  s->octree ? s->fnodes.p : nullptr, s->octree ? s->oblocks.p : nullptr, s->octree ? s->wlinks.p : nullptr, boxes[0].len2, max_inner_depth + 1};
     if (s->octree) {
         s->oct_lds = (size_t)std::max<uint32_t>(1u, max_inner_depth) * 12 * 64;  // 3 words per level per lane
         if (s->oct_lds > 64 * 1024) { s->octree = false; s->why_generic = "octree deeper than the LDS stack allows"; }
@@ -973,7 +999,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
             const uint32_t stride = quads * 4u;
             const size_t budget = 160u * 1024u / 8u - 2u * RTMI_POOL_MAX;
             const uint32_t P = (uint32_t)std::min<size_t>(RTMI_POOL_MAX, budget / (stride * 4u));
-            if (P >= 96u && hfn.size() / 4 < (1u << 22)) {
+            if (P >= 96u && hfn.size() / 2 < (1u << 22)) {
                 s->pool_P = P; s->pool_stride = stride;
                 s->pool_lds = (size_t)P * stride * 4u + 2u * RTMI_POOL_MAX;
                 nb = 0;
@@ -993,7 +1019,7 @@ int rtmi_scene_destroy(rtmi_scene_t* s) {
     if (!s) return RTMI_OK;
     (void)hipSetDevice(s->device);
     s->nodes.release(); s->refs.release(); s->tplane.release(); s->tedge.release(); s->mats.release();
-    s->fnodes.release(); s->oblocks.release();
+    s->fnodes.release(); s->oblocks.release(); s->wlinks.release();
     for (int k = 0; k < RTMI_MAX_STREAMS; k++) {
         s->w[k].release();
         if (s->istream[k]) (void)hipStreamDestroy(s->istream[k]);

@@ -35,9 +35,13 @@
 //    touches its own bank.
 //
 // Records (HBM, served from L2 / Infinity Cache):
-//   fnodes  : 4 x uint4 (64 B) per INNER box: (cx, cy, cz, child mask) link[0..3] link[4..7] (unused)
-//             link[o] of octant o: 0 = absent, bit 31 set = leaf (low bits: index of its first reference
-//             block), else index of the child's own record.  Leaves have no record.
+//   fnodes  : 2 x uint4 (32 B) per INNER box: (cx, cy, cz, present mask | leaf mask << 8 | FN_WIDE)
+//             (first inner child's record, first block of the first leaf child, 8 x u8 block offsets of the leaf
+//             children).  Children of a box are stored together: the inner ones as consecutive records in octant
+//             order, the leaf ones as consecutive runs of reference blocks in octant order, so a child's record /
+//             first block follows from the masks with a popcount / a byte extract.  Leaves have no record.  A box
+//             whose leaf children hold more than 255 blocks (FN_WIDE, rare) keeps 8 explicit 32-bit block indices in
+//             `wlinks` instead (one more dependent load).
 //   oblocks : uint4 blocks of triangle indices of a leaf, in list order.  The list ends at the first index 0
 //             (the sentinel triangle is never in a tree, raytrace.rs:791) or after a full block whose 4th
 //             index has bit 31 set.
@@ -56,6 +60,7 @@ enum : uint32_t { M_IDLE = 0, M_SELECT = 1, M_LEAF = 2 };
 // that already has a hit drops it (`NaN < t` is false) exactly like the running best does.
 #define O_DONE 0x100u
 #define O_HAS 0x200u
+#define FN_WIDE 0x10000u
 
 // v_max3_f32 / v_min3_f32: max(max(a,b),c) with fmaxf's NaN rule (a NaN operand is ignored), one instruction
 // instead of the two v_max + canonicalising moves hipcc emits for nested fmaxf.
@@ -168,8 +173,8 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                     }
                 }
                 if (mode == M_SELECT) {
-                    const uint4* fp = sc.fnodes + 4 * (size_t)fnode;
-                    const uint4 q0 = fp[0], q1 = fp[1], q2 = fp[2];
+                    const uint4* fp = sc.fnodes + 2 * (size_t)fnode;
+                    const uint4 q0 = fp[0], q1 = fp[1];
                     const float cx = __uint_as_float(q0.x), cy = __uint_as_float(q0.y), cz = __uint_as_float(q0.z);
                     const float hc = ldexpf(root_half, -(lvl + 1));  // half edge of the children (depth lvl + 1)
                     if (COUNT && (fw & 0xFFu) == 0u) { cnt[0] += __popc(q0.w & 0xFFu); cnt[3]++; }  // first visit: collides() on every child
@@ -225,20 +230,19 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                     bool ok = nh != 0u;
                     if (fw & O_HAS) ok = ok & (m1 < ft);
                     else ok = ok & (m1 != FLT_MAX);
-                    uint32_t bit = 0u, link = 0u;
-                    const uint32_t lk[8] = {q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+                    uint32_t bit = 0u;
 #pragma unroll
-                    for (int o = 7; o >= 0; o--) {
-                        const bool e = tm[o] == m1;
-                        bit = e ? (1u << o) : bit;
-                        link = e ? lk[o] : link;
-                    }
+                    for (int o = 7; o >= 0; o--) bit = (tm[o] == m1) ? (1u << o) : bit;
                     if (!ok) {
                         fw |= O_DONE;
                     } else {
                         fw |= bit | (nh == 1u ? O_DONE : 0u);  // nothing remains after the last candidate
-                        if (link >> 31) {
-                            lblock = link & 0x7FFFFFFFu;
+                        const uint32_t leafmask = (q0.w >> 8) & 0xFFu;
+                        if (leafmask & bit) {
+                            // first block of this leaf child: base + byte `octant` of the offsets
+                            const uint32_t oct = (uint32_t)__ffs((int)bit) - 1u;
+                            if (q0.w & FN_WIDE) lblock = sc.wlinks[(size_t)q1.y * 8u + oct];  // rare: explicit indices
+                            else lblock = q1.y + __builtin_amdgcn_ubfe(oct < 4u ? q1.z : q1.w, (oct & 3u) * 8u, 8u);
                             blk = sc.oblocks[lblock];
                             lhave = false; lt = 0.f; ltf = 0;
                             if (COUNT) cnt[4]++;
@@ -249,7 +253,9 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                             fr[NT] = fw;
                             fr[2 * NT] = __float_as_uint(ft);
                             lvl++;
-                            fnode = link; fw = 0u; ft = 0.f;
+                            // record of this inner child: the inner children before it in octant order
+                            fnode = q1.x + (uint32_t)__popc((q0.w & ~leafmask & 0xFFu) & (bit - 1u));
+                            fw = 0u; ft = 0.f;
                         }
                     }
                 }

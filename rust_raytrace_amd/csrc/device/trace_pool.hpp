@@ -146,8 +146,8 @@ __global__ void __launch_bounds__(64, 2) k_trace_pool(DScene sc, const float4* _
                     }
                 }
                 if (!finished) {
-                    const uint4* fp = sc.fnodes + 4 * (size_t)(fwn >> 10);
-                    const uint4 n0q = fp[0], n1q = fp[1], n2q = fp[2];
+                    const uint4* fp = sc.fnodes + 2 * (size_t)(fwn >> 10);
+                    const uint4 n0q = fp[0], n1q = fp[1];
                     const float cx = __uint_as_float(n0q.x), cy = __uint_as_float(n0q.y), cz = __uint_as_float(n0q.z);
                     const float hc = ldexpf(root_half, -(int)(lvl + 1u));  // half edge of the children (depth lvl + 1)
                     if (COUNT && (fwn & 0xFFu) == 0u) { cnt[0] += __popc(n0q.w & 0xFFu); cnt[3]++; }  // first visit: collides() on every child
@@ -186,20 +186,19 @@ __global__ void __launch_bounds__(64, 2) k_trace_pool(DScene sc, const float4* _
                     bool ok = nh != 0u;
                     if (fwn & O_HAS) ok = ok & (m1v < ft);   // raytrace.rs:965
                     else ok = ok & (m1v != FLT_MAX);         // raytrace.rs:986
-                    uint32_t bit = 0u, link = 0u;
-                    const uint32_t lk[8] = {n1q.x, n1q.y, n1q.z, n1q.w, n2q.x, n2q.y, n2q.z, n2q.w};
+                    uint32_t bit = 0u;
 #pragma unroll
-                    for (int o = 7; o >= 0; o--) {
-                        const bool e = tm[o] == m1v;
-                        bit = e ? (1u << o) : bit;
-                        link = e ? lk[o] : link;
-                    }
+                    for (int o = 7; o >= 0; o--) bit = (tm[o] == m1v) ? (1u << o) : bit;
                     if (!ok) {
                         fwn |= O_DONE;
                     } else {
                         fwn |= bit | (nh == 1u ? O_DONE : 0u);
-                        if (link >> 31) {
-                            const uint32_t lblock = link & 0x7FFFFFFFu;
+                        const uint32_t leafmask = (n0q.w >> 8) & 0xFFu;
+                        if (leafmask & bit) {
+                            const uint32_t oct = (uint32_t)__ffs((int)bit) - 1u;
+                            uint32_t lblock;
+                            if (n0q.w & FN_WIDE) lblock = sc.wlinks[(size_t)n1q.y * 8u + oct];
+                            else lblock = n1q.y + __builtin_amdgcn_ubfe(oct < 4u ? n1q.z : n1q.w, (oct & 3u) * 8u, 8u);
                             const uint4 blk = sc.oblocks[lblock];
                             st[15] = lblock;
                             q[4] = blk;
@@ -209,7 +208,8 @@ __global__ void __launch_bounds__(64, 2) k_trace_pool(DScene sc, const float4* _
                         } else {
                             *reinterpret_cast<uint2*>(st + 24u + 2u * lvl) = make_uint2(fwn, __float_as_uint(ft));
                             lvl++;
-                            fwn = link << 10; ft = 0.f;
+                            fwn = (n1q.x + (uint32_t)__popc((n0q.w & ~leafmask & 0xFFu) & (bit - 1u))) << 10;
+                            ft = 0.f;
                         }
                     }
                     st[7] = lvl;

@@ -219,7 +219,7 @@ def test_small_batches_same_image(canonical_pair):
         R.HipRayCaster(seed=3, tuning=tn).walk_rays(vp, sp, c, 1, False)
         assert_bits_equal(a, c, f"tuning {tn}")
     with pytest.raises(RuntimeError):
-        R.HipRayCaster(seed=3, tuning={"streams": 3}).walk_rays(vp, sp, b, 1, False)
+        R.HipRayCaster(seed=3, tuning={"streams": 9}).walk_rays(vp, sp, b, 1, False)  # more than RTMI_MAX_STREAMS
 
 
 def test_quantize_matches_oracle(canonical_pair):
