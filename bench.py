@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--u8", action="store_true",
                     help="quantise every band on its GPU ((c*255.) as u8, raytrace.rs:1468-1473) and gather 3 B/pixel instead of 16")
     ap.add_argument("--fast", action="store_true", help="RTMI_OPT_FAST (not bit-exact, NOT the headline): skip boxes behind the ray origin")
+    ap.add_argument("--bvh", action="store_true",
+                    help="RTMI_OPT_BVH fast mode (NOT the headline): linear-list semantics through the library's SAH BVH; "
+                         "prints the differing-pixel count against the exact octree render")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, one rank per GPU) or gloo (rehearsal: ranks may share a GPU)")
     ap.add_argument("--check", action="store_true", help="rank 0 verifies the gathered frame against a single-tile render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,7 +151,7 @@ def main():
     t_build = time.time() - t0
     W, H, spp = args.width, args.height, args.spp
     vp = R.canonical_viewport(W, H, args.maxdepth, spp)
-    caster = R.HipRayCaster(seed=args.seed, device=local_rank, options=R.OPT_FAST if args.fast else 0)
+    caster = R.HipRayCaster(seed=args.seed, device=local_rank, options=(R.OPT_FAST if args.fast else 0) | (R.OPT_BVH if args.bvh else 0))
     t0 = time.time()
     caster.upload(scene)
     t_upload = time.time() - t0
@@ -227,10 +230,19 @@ def main():
             d2 = time.perf_counter() - t1
             incl_d2h = {"value": round(rays / args.steps * n2 / d2 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(d2 / n2 * 1e3, 3),
                         "note": f"timed window also contains the {host.numel() * host.element_size() >> 20} MiB frame copy to pinned host memory"}
-        if world == 1 and not args.no_counters:
+        if world == 1 and not args.no_counters and not args.bvh:
             roofline = roofline_object(args, caster, scene, vp, tile, local, stream, rays / args.steps, trace_ms, kernel_ms, launches, dt)
         if world == 1 and not args.no_cpu_baseline and args.scene == "canonical":
             cpu_baseline = cpu_baseline_object(args, obj)
+        fast_vs_exact = None
+        if (args.bvh or args.fast) and world == 1:
+            # how far the opt-in mode is from the exact (default) render of the same frame
+            ex = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+            ectx = R.HipRayCaster(seed=args.seed, device=local_rank).walk_tile_device(vp, scene, (0, H, H, 0), ex.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            diff = (ex.view(torch.int32) != frame.view(torch.int32)).any(dim=2)
+            fast_vs_exact = {"differing_pixels": int(diff.sum()), "pixels": H * W, "max_abs_diff": float((ex - frame).abs().max()),
+                             "rays_exact": int(ectx.total_rays), "rays_this_mode": int(rays / args.steps)}
         if args.check:
             ref = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
             caster.walk_tile_device(vp, scene, (0, H, H, 0), ref.data_ptr(), stream.cuda_stream)
@@ -251,7 +263,8 @@ def main():
                     "grid": "config 5: 8 x teapot_tri.obj grid (50561 triangles), octree (10,19), ",
                     "linear": "config 2: canonical scene from teapot.obj, trivial bounding box (linear list of 6720 triangles), "}[args.scene]
         workload += f"{W}x{H} @ {spp} spp, depth {args.maxdepth}, seed {args.seed}" + (" [RTMI_OPT_FAST: not bit-exact]" if args.fast else "")
-        headline = args.scene == "canonical" and (W, H, spp) == (2048, 2048, 64) and not args.fast
+        workload += " [RTMI_OPT_BVH fast mode: linear-list semantics, NOT the octree traversal]" if args.bvh else ""
+        headline = args.scene == "canonical" and (W, H, spp) == (2048, 2048, 64) and not args.fast and not args.bvh
         out = {
             "metric": "Mrays/s (primary + bounce rays per second of frame time)" + (", teapot_tri.obj 2048x2048 @64spp" if headline else f", BASELINE config {args.config} workload, see config.workload"),
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -262,7 +275,7 @@ def main():
                        "rays_per_frame": int(rays / args.steps)},
             "ranks": {"n_ranks_seen": n_ranks_seen, "backend": args.backend if world > 1 else None,
                       "render_ms_per_rank": rank_render_ms, "gather_ms_per_rank": rank_gather_ms},
-            "value_incl_frame_d2h": incl_d2h,
+            "value_incl_frame_d2h": incl_d2h, "opt_in_mode_vs_exact": fast_vs_exact,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "setup": {"octree_build_s": round(t_build, 2), "scene_upload_s": round(t_upload, 3)},
         }

@@ -112,11 +112,19 @@ int rtmi_scene_destroy(rtmi_scene_t* scene);
 enum {
     RTMI_OPT_COUNTERS = 1u << 0, /* fill box/tri/node counters in rtmi_stats_t (slower) */
     RTMI_OPT_GENERIC = 1u << 1,  /* force the generic-tree traversal kernel              */
-    RTMI_OPT_FAST = 1u << 2      /* NOT bit-exact: skip boxes entirely behind the ray origin (octree kernel only).
+    RTMI_OPT_FAST = 1u << 2,     /* NOT bit-exact: skip boxes entirely behind the ray origin (octree kernel only).
                                   * The reference visits them; results differ only where a hit would have been found
                                   * first through such a box (exact ties between triangles, rays exactly parallel to a
                                   * triangle's plane).  Measured on config 3 (2048x2048 @ 64 spp): 17 of 4 194 304
                                   * pixels differ from exact mode, 1.6x the rays/s.  Never the default.              */
+    RTMI_OPT_BVH = 1u << 3       /* "fast mode", NOT the reference's octree traversal: the closest hit over ALL triangles
+                                  * with the lowest index winning exact ties, i.e. what the reference computes for a
+                                  * build_trivial_bounding_box scene (raytrace.rs:847-856, :1012-1050), found through a
+                                  * SAH BVH the library builds over the triangles' bounding spheres at scene creation (the
+                                  * boxes/tri_refs passed in are ignored for tracing).  Bit-equal to the linear-list
+                                  * render except for the reference's t = +-inf / NaN "hits" of triangles a ray does not
+                                  * come near; differs from the octree render where the octree builder lost a triangle
+                                  * or two triangles tie.  Never the default, never the headline.                     */
 };
 int rtmi_scene_set_options(rtmi_scene_t* scene, uint32_t options);
 

@@ -224,6 +224,12 @@ def kat_face_collision():
     return int(lib().orc_kat_face_collision())
 
 
+def set_finite_hits_only(on):
+    """NOT the reference: ignore "hits" with a +-inf / NaN time (rays exactly parallel to a triangle's plane).  This is
+    the definition of the product's opt-in RTMI_OPT_BVH mode; only the test of that mode switches it on (and off again)."""
+    lib().orc_set_finite_hits_only(C.c_int(1 if on else 0))
+
+
 def quantize(rgba):
     rgba = _f(rgba).reshape(-1, 4)
     out = np.zeros((rgba.shape[0], 3), np.uint8)

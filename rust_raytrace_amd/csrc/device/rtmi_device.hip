@@ -341,6 +341,7 @@ __global__ void __launch_bounds__(256) k_trace(DScene sc, const float4* __restri
 #include "build_octree.hpp"
 #include "trace_oct.hpp"
 #include "trace_pool.hpp"
+#include "bvh_fast.hpp"
 namespace rtmi {
 
 
@@ -724,6 +725,13 @@ struct rtmi_scene {
     DevBuf<float4> tplane, tedge, mats;
     DevBuf<uint4> fnodes, oblocks;
     DevBuf<uint32_t> wlinks;
+    // RTMI_OPT_BVH: SAH BVH over the triangles' bounding spheres (bvh_fast.hpp)
+    DevBuf<float4> bnodes;
+    DevBuf<uint4> bleaves;
+    uint32_t bvh_root = 0;
+    size_t bvh_lds = 0;
+    int bvh_blocks_per_cu = 8;
+    bool bvh_ok = false;
     bool root_is_leaf = false; // build_trivial_bounding_box: one list for every ray -> k_trace_linear
     bool octree = false;       // the tree passed the exact-octree check
     std::string why_generic;   // reason when it did not
@@ -1009,6 +1017,23 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
             }
         }
     }
+    {   // fast-mode BVH (cheap: binned SAH over bounding spheres); absent when a record is not finite
+        BvhBuild bb;
+        if (bvh_build(tris, ntris, bb)) {
+            if (bb.nodes.empty()) bb.nodes.resize(4, make_float4(0.f, 0.f, 0.f, 0.f));
+            hipError_t be = up(s->bnodes, bb.nodes);
+            if (be == hipSuccess) be = up(s->bleaves, bb.leaves);
+            if (be != hipSuccess) return fail(hip_code(be), std::string("scene upload (BVH): ") + hipGetErrorString(be));
+            s->bvh_root = bb.root_link;
+            s->bvh_lds = (size_t)(bb.depth + 2) * 64 * 4;
+            int nb = 0;
+            if (s->bvh_lds <= 64 * 1024 &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_bvh<false>, 64, s->bvh_lds) == hipSuccess && nb > 0) {
+                s->bvh_blocks_per_cu = nb;
+                s->bvh_ok = true;
+            }
+        }
+    }
     own.s = nullptr;
     *out = s;
     return RTMI_OK;
@@ -1019,7 +1044,7 @@ int rtmi_scene_destroy(rtmi_scene_t* s) {
     if (!s) return RTMI_OK;
     (void)hipSetDevice(s->device);
     s->nodes.release(); s->refs.release(); s->tplane.release(); s->tedge.release(); s->mats.release();
-    s->fnodes.release(); s->oblocks.release(); s->wlinks.release();
+    s->fnodes.release(); s->oblocks.release(); s->wlinks.release(); s->bnodes.release(); s->bleaves.release();
     for (int k = 0; k < RTMI_MAX_STREAMS; k++) {
         s->w[k].release();
         if (s->istream[k]) (void)hipStreamDestroy(s->istream[k]);
@@ -1082,7 +1107,11 @@ template <bool COUNT>
 static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* qo, const float4* qd, int pass, hipEvent_t stop) {
     // `stop` is recorded right after the closest-hit kernel, so that the event pair of the caller times exactly
     // the kernel rocprofv3 lists as k_trace_oct / k_trace_linear / k_trace
-    if (s->root_is_leaf && !(s->options & RTMI_OPT_GENERIC)) {
+    if ((s->options & RTMI_OPT_BVH) && s->bvh_ok) {
+        const dim3 grid((unsigned)(s->num_cu * s->bvh_blocks_per_cu)), block(64);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_bvh<COUNT>), grid, block, s->bvh_lds, st, s->d, s->bnodes.p, s->bleaves.p, s->bvh_root,
+                           qo, qd, w.ctrl.p, pass, w.hit_tf.p, w.hit_t.p, (int)(pass == 0 ? s->tune.refill_min0 : s->tune.refill_min));
+    } else if (s->root_is_leaf && !(s->options & RTMI_OPT_GENERIC)) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_linear<COUNT>), dim3((unsigned)(s->num_cu * 8)), dim3(256), 0, st, s->d, qo, qd,
                            w.ctrl.p, pass, w.hit_tf.p, w.hit_t.p);
     } else if (s->octree && !(s->options & RTMI_OPT_GENERIC)) {

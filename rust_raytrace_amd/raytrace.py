@@ -14,7 +14,7 @@ import numpy as np
 from . import _ffi
 
 SOLID, MATTE, REFLECTIVE = 0, 1, 2
-OPT_COUNTERS, OPT_GENERIC, OPT_FAST = 1, 2, 4
+OPT_COUNTERS, OPT_GENERIC, OPT_FAST, OPT_BVH = 1, 2, 4, 8
 
 
 def _f(a):

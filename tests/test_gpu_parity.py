@@ -703,3 +703,104 @@ def test_pool_kernel_is_bit_exact(canonical_pair):
     img = np.zeros((33, 33, 4), np.float32)
     R.HipRayCaster(tuning={"kernel": 2}).walk_rays(vp, pair[1], img, 1, False)
     assert_bits_equal(ref, img, "pool kernel, axis-aligned scene")
+
+
+def test_bvh_fast_mode_equals_linear_list_oracle(canonical_pair):
+    """RTMI_OPT_BVH (opt-in "fast mode", never the default): the closest hit over ALL triangles with the lowest index
+    winning ties, found through the library's SAH BVH.  Its oracle is the REFERENCE's own linear-list semantics: the same
+    triangles under build_trivial_bounding_box (raytrace.rs:847-856, one leaf scanned in index order, :1012-1050), with
+    the mode's one stated exception: "hits" with a +-inf / NaN time (rays exactly parallel to a triangle's plane, which
+    the reference accepts wherever the triangle is) are ignored -- orc_set_finite_hits_only.  Bit-equal hit ids / times /
+    faces for primary and random rays and a bit-equal frame; how many pixels that exception and the octree's own
+    deviations cost is counted."""
+    from conftest import TEAPOT_TRI
+    orc, R = _orc(), _R()
+    orc.set_finite_hits_only(True)
+    try:
+        _bvh_vs_linear(canonical_pair, orc, R, TEAPOT_TRI)
+    finally:
+        orc.set_finite_hits_only(False)
+
+
+def _bvh_vs_linear(canonical_pair, orc, R, TEAPOT_TRI):
+    so_oct, sp = canonical_pair
+    so_lin = orc.canonical_scene(TEAPOT_TRI, accel="trivial")      # same triangles, the reference's linear list
+    vo = orc.canonical_viewport(64, 64)
+    o4, d4 = orc.primary_rays(64, 64, vo, 1)
+    rng = np.random.default_rng(11)
+    n = 6000
+    ro = np.zeros((n, 4), np.float32)
+    rd = np.zeros((n, 4), np.float32)
+    ro[:, :3] = rng.uniform(-6, 6, (n, 3)) + np.array([0, 0, 6])
+    d = rng.normal(size=(n, 3))
+    rd[:, :3] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    o4, d4 = np.concatenate([o4, ro]), np.concatenate([d4, rd])
+    tri_o, t_o, face_o, _ = so_lin.trace(o4, d4)
+    tri_g, t_g, face_g, st = R.HipRayCaster(options=R.OPT_BVH).trace(sp, o4, d4)
+    assert np.array_equal(tri_o, tri_g), f"{(tri_o != tri_g).sum()} hit ids differ"
+    hit = tri_o != 0
+    assert hit.sum() > 1000
+    assert_bits_equal(t_o[hit], t_g[hit], "hit time")
+    assert np.array_equal(face_o[hit], face_g[hit])
+    # a seeded frame: BVH mode == the oracle's linear-list render, bit for bit, same ray count
+    w, h, spp = 48, 40, 3
+    vo = orc.canonical_viewport(w, h)
+    vp = R.canonical_viewport(w, h, 5, spp)
+    ref_lin, cn = so_lin.render(w, h, vo, 5, spp, seed=7, threads=8)
+    img = np.zeros((h, w, 4), np.float32)
+    ctx = R.HipRayCaster(seed=7, options=R.OPT_BVH).walk_rays(vp, sp, img, 1, False)
+    assert_bits_equal(ref_lin, img, "BVH mode vs linear-list oracle")
+    assert ctx.total_rays == cn["rays"]
+    # the stated exception, counted: the reference's linear list WITH its parallel-plane hits
+    orc.set_finite_hits_only(False)
+    ref_lin_all, _ = so_lin.render(w, h, vo, 5, spp, seed=7, threads=8)
+    n_inf = int((ref_lin_all.view(np.uint32) != img.view(np.uint32)).any(axis=2).sum())
+    # and the default stays the exact octree traversal
+    ref_oct, _ = so_oct.render(w, h, vo, 5, spp, seed=7, threads=8)
+    exact = np.zeros_like(img)
+    R.HipRayCaster(seed=7).walk_rays(vp, sp, exact, 1, False)
+    assert_bits_equal(ref_oct, exact, "default mode stays exact")
+    differing = int((exact.view(np.uint32) != img.view(np.uint32)).any(axis=2).sum())
+    print(f"BVH mode: {n_inf} of {w * h} pixels differ from the reference's linear list (parallel-plane hits), {differing} from the octree render")
+    assert n_inf <= 8 and differing <= 8
+
+
+def test_bvh_fast_mode_other_scenes():
+    """BVH mode on the circles scene (tessellated spheres, Solid / Matte / Reflective) and on random triangle soups,
+    against the oracle's linear list of the same triangles."""
+    from conftest import OracleApi, ProductApi
+    orc, R = _orc(), _R()
+    orc.set_finite_hits_only(True)
+    try:
+        _bvh_other(orc, R, OracleApi, ProductApi)
+    finally:
+        orc.set_finite_hits_only(False)
+
+
+def _bvh_other(orc, R, OracleApi, ProductApi):
+    so, sp = build_pair(recipe_circles(accel="trivial"))
+    vo = orc.canonical_viewport(64, 64)
+    vp = R.canonical_viewport(64, 64, 5, 2)
+    ref, cn = so.render(64, 64, vo, 5, 2, seed=3, threads=8)
+    img = np.zeros((64, 64, 4), np.float32)
+    ctx = R.HipRayCaster(seed=3, options=R.OPT_BVH).walk_rays(vp, sp, img, 1, False)
+    assert_bits_equal(ref, img, "circles, BVH mode")
+    assert ctx.total_rays == cn["rays"]
+    rng = np.random.default_rng(99)
+    pts = (rng.uniform(-3, 3, (300, 1, 3)) + np.array([0, 0, 8.0]) + rng.normal(scale=0.6, size=(300, 3, 3))).astype(np.float32)
+
+    def recipe(api):
+        s = api.scene()
+        for i in range(len(pts)):
+            try:
+                api.add_triangle(s, pts[i], api.matte((200, 100, 50), 0.4) if i % 2 else api.solid((20, 200, 40)), 0.05 if i % 3 else 0.0)
+            except RuntimeError:
+                pass
+        s.populate_triangle_numbers()
+        s.build_trivial_bounding_box([0.0, 0.0, 8.0], 8.0)
+        return s
+    so, sp = recipe(OracleApi(orc)), recipe(ProductApi(R))
+    ref, cn = so.render(40, 28, orc.canonical_viewport(40, 28), 4, 3, seed=5, threads=8)
+    img = np.zeros((28, 40, 4), np.float32)
+    R.HipRayCaster(seed=5, options=R.OPT_BVH).walk_rays(R.canonical_viewport(40, 28, 4, 3), sp, img, 1, False)
+    assert_bits_equal(ref, img, "triangle soup, BVH mode")
