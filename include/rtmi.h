@@ -93,6 +93,22 @@ typedef struct rtmi_tile {
     uint32_t row0, nrows, stripe_rows, stripe_step;
 } rtmi_tile_t;
 
+/* Analytic sphere.  NOT part of the reference at this revision (its only `Collidable` is `Triangle`, raytrace.rs:399;
+ * spheres are tessellated by make_sphere, raytrace.rs:464-529); BASELINE's north_star names an analytic ray-sphere
+ * test, so this build defines one -- parity with the Rust binary is unpinned by construction.  Semantics (the oracle's
+ * `struct Sphere` states them in full): standard quadratic in the reference's Vec3 arithmetic, `t < 0` is a miss like
+ * for triangles, the far root counts as a Back-face hit from inside, normal = (point - center).unit(); no edge faces.
+ * A scene's spheres are a flat list: every ray is tested against every sphere AFTER the box tree and a sphere replaces
+ * the tree's hit iff it is strictly closer.  Reported hit index = ntris + sphere index. */
+typedef struct rtmi_sphere {
+    float center[3];
+    float radius;
+    uint32_t surface_kind; /* RTMI_SOLID / RTMI_MATTE / RTMI_REFLECTIVE */
+    float color[3];
+    float alpha;
+    float scattering;
+} rtmi_sphere_t;
+
 typedef struct rtmi_scene rtmi_scene_t;
 
 /* Number of visible HIP devices (0 when none); never fails. */
@@ -107,6 +123,9 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris,
                       const uint32_t* tri_refs, uint64_t nrefs,
                       int device, rtmi_scene_t** out);
 int rtmi_scene_destroy(rtmi_scene_t* scene);
+
+/* Replace the scene's list of analytic spheres (n may be 0).  At most 4096 spheres (they are not in the tree). */
+int rtmi_scene_set_spheres(rtmi_scene_t* scene, const rtmi_sphere_t* spheres, uint64_t n);
 
 /* Option switches (all default 0): */
 enum {

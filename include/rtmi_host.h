@@ -51,6 +51,9 @@ int rth_add_sphere(rth_scene_t* s, const float* orig3, float r, uint64_t num_lat
 /* n triangles at once through the GPU make_triangle kernel (rtmi_make_triangles) */
 int rth_add_triangles_gpu(rth_scene_t* s, const float* pts9, uint64_t n, uint32_t kind, const float* color3, float alpha,
                           float scattering, float edge, int device);
+/* analytic sphere: a build-defined extension (rtmi_sphere_t in rtmi.h), not a reference API */
+int rth_add_analytic_sphere(rth_scene_t* s, const float* center3, float radius, uint32_t kind, const float* color3, float alpha,
+                            float scattering);
 void rth_populate_triangle_numbers(rth_scene_t* s);
 
 /* build_bounding_box / build_trivial_bounding_box into Scene.boxes */

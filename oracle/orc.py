@@ -121,6 +121,17 @@ class Scene:
         self._check(lib().orc_add_sphere(self.h, _p(_f(orig)), C.c_float(r), C.c_uint64(lat_lon[0]),
                                          C.c_uint64(lat_lon[1]), *surface.args(), C.c_float(edge)))
 
+    def add_analytic_sphere(self, center, r, surface):
+        """Build-defined extension (the reference has no analytic sphere: parity unpinned, see rt_oracle.cpp struct Sphere)."""
+        self._check(lib().orc_add_analytic_sphere(self.h, _p(_f(center)), C.c_float(r), *surface.args()))
+
+    def trace_spheres(self, o4, d4):
+        o4, d4 = _f(o4).reshape(-1, 4), _f(d4).reshape(-1, 4)
+        n = o4.shape[0]
+        idx, t, face = np.zeros(n, np.uint32), np.zeros(n, np.float32), np.zeros(n, np.uint32)
+        lib().orc_trace_spheres(self.h, C.c_uint64(n), _p(o4), _p(d4), _p(idx), _p(t), _p(face))
+        return idx, t, face
+
     def populate_triangle_numbers(self):
         lib().orc_populate_triangle_numbers(self.h)
 

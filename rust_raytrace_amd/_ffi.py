@@ -85,6 +85,7 @@ def lib():
     L.rth_add_disk.argtypes = [vp, vp, vp, f32, f32, u64, u32, vp, f32, f32, u32, vp, f32, f32, f32]
     L.rth_add_sphere.argtypes = [vp, vp, f32, u64, u64, u32, vp, f32, f32, f32]
     L.rth_populate_triangle_numbers.argtypes = [vp]
+    L.rth_add_analytic_sphere.argtypes = [vp, vp, f32, u32, vp, f32, f32]
     L.rth_build_bounding_box.argtypes = [vp, vp, f32, u64, u64, u32]
     L.rth_build_bounding_box_gpu.argtypes = [vp, vp, f32, u64, u64, i32]
     L.rth_build_trivial_bounding_box.argtypes = [vp, vp, f32]
@@ -110,11 +111,11 @@ def lib():
 
 # every symbol include/rtmi.h and include/rtmi_host.h declare
 RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_set_options",
-                "rtmi_scene_get_tuning", "rtmi_scene_set_tuning", "rtmi_render", "rtmi_render_frame_multi",
+                "rtmi_scene_get_tuning", "rtmi_scene_set_tuning", "rtmi_scene_set_spheres", "rtmi_render", "rtmi_render_frame_multi",
                 "rtmi_render_device", "rtmi_render_tile_device", "rtmi_trace", "rtmi_quantize", "rtmi_quantize_device", "rtmi_make_triangles", "rtmi_builder_create", "rtmi_builder_filter", "rtmi_builder_destroy", "rtmi_last_error"]
 RTH_SYMBOLS = ["rth_last_error", "rth_make_color", "rth_unit", "rth_to_radians", "rth_create_transform",
                "rth_create_viewport", "rth_scene_new", "rth_scene_free", "rth_num_tris", "rth_add_triangle", "rth_add_triangles_gpu", "rth_add_obj", "rth_add_obj_mode",
-               "rth_add_disk", "rth_add_sphere", "rth_populate_triangle_numbers", "rth_build_bounding_box", "rth_build_bounding_box_gpu",
+               "rth_add_disk", "rth_add_sphere", "rth_add_analytic_sphere", "rth_populate_triangle_numbers", "rth_build_bounding_box", "rth_build_bounding_box_gpu",
                "rth_build_trivial_bounding_box", "rth_box_contains_polygon", "rth_face_contains_triangle",
                "rth_get_triangles", "rth_tree_sizes", "rth_tree_get", "rth_caster_config", "rth_caster_walk_rows",
                "rth_caster_walk_rows_device", "rth_caster_walk_tile_device", "rth_caster_trace", "rth_caster_upload", "rth_caster_set_tuning", "rth_caster_set_devices", "rth_caster_walk_frame_multi", "rth_caster_quantize_device", "rth_quantize"]

@@ -62,6 +62,9 @@ struct DScene {
     const uint4* fnodes;
     const uint4* oblocks;
     const uint32_t* wlinks;  // 8 explicit first-block indices per FN_WIDE box
+    // analytic spheres (a build-defined extension, rtmi_sphere_t): 2 x float4 each, (centre, radius) (surface id, 0, 0, 0)
+    const float4* spheres;
+    uint32_t nspheres;
     float root_half;
     uint32_t olevels;
 };
@@ -541,8 +544,11 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed
             } else if (face & 2u) {
                 c = mk(0.f / 255.f, 0.f / 255.f, 0.f / 255.f);  // edge faces are Solid black, raytrace.rs:452-457
             } else {
-                const float4 p1 = sc.tplane[2 * tri + 1];
-                const uint32_t mat = __float_as_uint(p1.w);
+                // a triangle's record, or (hit index >= ntris) an analytic sphere's: the sphere's normal needs the hit
+                // point and is filled in below
+                const bool is_sphere = tri >= sc.ntris;
+                const float4 p1 = is_sphere ? sc.spheres[2 * (tri - sc.ntris) + 1] : sc.tplane[2 * tri + 1];
+                const uint32_t mat = __float_as_uint(is_sphere ? p1.x : p1.w);
                 const float4 m0 = sc.mats[2 * mat], m1 = sc.mats[2 * mat + 1];
                 const uint32_t kind = __float_as_uint(m1.y);
                 if (kind == RTMI_SOLID) {
@@ -557,6 +563,10 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed
                         const float t = hit_t[i];
                         const V4 point = vadd(vmul(rd, t), ro);                      // Ray::at, raytrace.rs:227-229
                         V4 norm = mk(p1.x, p1.y, p1.z);
+                        if (is_sphere) {  // (point - center).unit()
+                            const float4 sc0 = sc.spheres[2 * (tri - sc.ntris)];
+                            norm = vunit(vsub(point, mk(sc0.x, sc0.y, sc0.z)));
+                        }
                         if (face & 1u) norm = vmul(norm, -1.f);                       // raytrace.rs:441-449
                         const V4 rv = random_vec(seed, pixel, sample, (uint32_t)pass + 1);
                         if (kind == RTMI_MATTE) {
@@ -649,6 +659,39 @@ __global__ void __launch_bounds__(256) k_deinterleave(const uint8_t* __restrict_
     }
 }
 
+// Analytic spheres (rtmi_sphere_t; a build-defined extension, see include/rtmi.h): every ray of the pass against the
+// scene's flat sphere list, after the tree's closest hit.  4-lane arithmetic exactly as the oracle's sphere_intersects.
+__global__ void __launch_bounds__(256) k_trace_spheres(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
+                                                       const DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
+                                                       float* __restrict__ hit_t) {
+    const uint32_t count = ctrl->count[pass];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float4 o4 = qo[i], d4 = qd[i];
+        const V4 ro{o4.x, o4.y, o4.z, o4.w}, rd{d4.x, d4.y, d4.z, d4.w};
+        uint32_t tf = hit_tf[i];
+        float bt = hit_t[i];
+        bool have = tf != 0u;
+        for (uint32_t k = 0; k < sc.nspheres; k++) {
+            const float4 s0 = sc.spheres[2 * k];
+            const V4 oc = vsub(ro, mk(s0.x, s0.y, s0.z));
+            const float b = vdot(oc, rd);
+            const float c = vlen2(oc) - s0.w * s0.w;
+            const float disc = b * b - c;
+            if (!(disc >= 0.f)) continue;
+            const float sq = sqrtf(disc);
+            const float t0 = (0.f - b) - sq, t1 = (0.f - b) + sq;
+            float t; uint32_t face;
+            if (t0 >= 0.f) { t = t0; face = 0u; }
+            else if (t1 >= 0.f) { t = t1; face = 1u; }
+            else continue;
+            if (!have || t < bt) { bt = t; tf = (sc.ntris + k) | (face << 30); have = true; }
+        }
+        hit_tf[i] = tf;
+        hit_t[i] = bt;
+    }
+}
+
 // Explicit-ray entry (rtmi_trace): queue = the caller's rays
 __global__ void k_set_count(DCtrl* ctrl, uint32_t n) { ctrl->count[0] = n; }
 
@@ -722,7 +765,8 @@ struct rtmi_scene {
     DScene d{};
     DevBuf<DNode> nodes;
     DevBuf<uint32_t> refs;
-    DevBuf<float4> tplane, tedge, mats;
+    DevBuf<float4> tplane, tedge, mats, spheres;
+    std::vector<float4> hmats;  // the triangles' surface table (host copy): sphere surfaces are appended to it
     DevBuf<uint4> fnodes, oblocks;
     DevBuf<uint32_t> wlinks;
     // RTMI_OPT_BVH: SAH BVH over the triangles' bounding spheres (bvh_fast.hpp)
@@ -992,7 +1036,8 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     if (e != hipSuccess) return fail(hip_code(e), std::string("scene upload: ") + hipGetErrorString(e));
     s->d = DScene{s->nodes.p, s->refs.p, s->tplane.p, s->tedge.p, s->mats.p,
                   (uint32_t)nboxes, (uint32_t)ntris, (uint32_t)matmap.size(), levels,
-                  s->octree ? s->fnodes.p : nullptr, s->octree ? s->oblocks.p : nullptr, s->octree ? s->wlinks.p : nullptr, boxes[0].len2, max_inner_depth + 1};
+                  s->octree ? s->fnodes.p : nullptr, s->octree ? s->oblocks.p : nullptr, s->octree ? s->wlinks.p : nullptr, nullptr, 0u, boxes[0].len2, max_inner_depth + 1};
+    s->hmats = hm;
     if (s->octree) {
         s->oct_lds = (size_t)std::max<uint32_t>(1u, max_inner_depth) * 12 * 64;  // 3 words per level per lane
         if (s->oct_lds > 64 * 1024) { s->octree = false; s->why_generic = "octree deeper than the LDS stack allows"; }
@@ -1044,7 +1089,7 @@ int rtmi_scene_destroy(rtmi_scene_t* s) {
     if (!s) return RTMI_OK;
     (void)hipSetDevice(s->device);
     s->nodes.release(); s->refs.release(); s->tplane.release(); s->tedge.release(); s->mats.release();
-    s->fnodes.release(); s->oblocks.release(); s->wlinks.release(); s->bnodes.release(); s->bleaves.release();
+    s->fnodes.release(); s->oblocks.release(); s->wlinks.release(); s->bnodes.release(); s->bleaves.release(); s->spheres.release();
     for (int k = 0; k < RTMI_MAX_STREAMS; k++) {
         s->w[k].release();
         if (s->istream[k]) (void)hipStreamDestroy(s->istream[k]);
@@ -1062,6 +1107,39 @@ int rtmi_scene_set_options(rtmi_scene_t* s, uint32_t options) {
     if (!s) return fail(RTMI_ERR_INVALID, "scene is NULL");
     s->options = options;
     return RTMI_OK;
+}
+
+int rtmi_scene_set_spheres(rtmi_scene_t* s, const rtmi_sphere_t* sp, uint64_t n) {
+    if (!s) return fail(RTMI_ERR_INVALID, "scene is NULL");
+    if (n && !sp) return fail(RTMI_ERR_INVALID, "spheres is NULL");
+    if (n > 4096) return fail(RTMI_ERR_UNSUPPORTED, "more than 4096 analytic spheres (they are a flat list, not in the tree)");
+    if ((uint64_t)s->d.ntris + n >= (1ull << 30)) return fail(RTMI_ERR_UNSUPPORTED, "hit index space exhausted");
+    RTMI_GUARD_BEGIN
+    auto fbits = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+    std::vector<float4> mats = s->hmats, rec(2 * n);
+    for (uint64_t i = 0; i < n; i++) {
+        if (sp[i].surface_kind > RTMI_REFLECTIVE) return fail(RTMI_ERR_INVALID, "unknown surface kind");
+        const float alpha = sp[i].surface_kind == RTMI_SOLID ? 0.f : sp[i].alpha;
+        const float scat = sp[i].surface_kind == RTMI_REFLECTIVE ? sp[i].scattering : 0.f;
+        const uint32_t mid = (uint32_t)(mats.size() / 2);
+        mats.push_back(make_float4(sp[i].color[0], sp[i].color[1], sp[i].color[2], alpha));
+        mats.push_back(make_float4(scat, fbits(sp[i].surface_kind), 0.f, 0.f));
+        rec[2 * i] = make_float4(sp[i].center[0], sp[i].center[1], sp[i].center[2], sp[i].radius);
+        rec[2 * i + 1] = make_float4(fbits(mid), 0.f, 0.f, 0.f);
+    }
+    if (mats.size() / 2 > 65535) return fail(RTMI_ERR_UNSUPPORTED, "more than 65535 distinct surfaces");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());  // no render of this scene is in flight (one call at a time per handle)
+    HIPCHK(s->mats.ensure(std::max<size_t>(mats.size(), 1)));
+    HIPCHK(hipMemcpy(s->mats.p, mats.data(), mats.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK(s->spheres.ensure(std::max<size_t>(rec.size(), 1)));
+    if (n) HIPCHK(hipMemcpy(s->spheres.p, rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
+    s->d.mats = s->mats.p;
+    s->d.nmats = (uint32_t)(mats.size() / 2);
+    s->d.spheres = s->spheres.p;
+    s->d.nspheres = (uint32_t)n;
+    return RTMI_OK;
+    RTMI_GUARD_END
 }
 
 int rtmi_scene_get_tuning(rtmi_scene_t* s, rtmi_tuning_t* out) {
@@ -1143,6 +1221,8 @@ static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* q
                            w.hit_tf.p, w.hit_t.p);
     }
     (void)hipEventRecord(stop, st);
+    if (s->d.nspheres)  // analytic spheres: a flat list against every ray, after the tree (not part of the timed trace kernel)
+        hipLaunchKernelGGL(k_trace_spheres, dim3((unsigned)(s->num_cu * 8)), dim3(256), 0, st, s->d, qo, qd, w.ctrl.p, pass, w.hit_tf.p, w.hit_t.p);
 }
 }  // extern "C++"
 

@@ -109,6 +109,12 @@ int rth_add_triangles_gpu(rth_scene_t* s, const float* p, uint64_t n, uint32_t k
         s->scene.touch();
     });
 }
+int rth_add_analytic_sphere(rth_scene_t* s, const float* center3, float r, uint32_t kind, const float* c, float alpha, float scat) {
+    return guarded([&] {
+        s->scene.spheres.push_back(Sphere{v3(center3), r, surf(kind, c, alpha, scat)});
+        s->scene.touch();
+    });
+}
 void rth_populate_triangle_numbers(rth_scene_t* s) { populate_triangle_numbers(s->scene.tris); s->scene.touch(); }
 
 int rth_build_bounding_box(rth_scene_t* s, const float* orig3, float len2, uint64_t maxdepth, uint64_t minobjs, uint32_t threads) {

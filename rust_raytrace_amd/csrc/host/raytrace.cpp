@@ -603,6 +603,22 @@ rtmi_scene_t* HipRayCaster::resident(const Scene& s) {
         }
         extra_.push_back(e);
     }
+    if (!s.spheres.empty()) {
+        std::vector<rtmi_sphere_t> sp(s.spheres.size());
+        for (size_t i = 0; i < sp.size(); i++) {
+            const Sphere& q = s.spheres[i];
+            for (int k = 0; k < 3; k++) { sp[i].center[k] = q.center.v[k]; sp[i].color[k] = q.surface.color.v[k]; }
+            sp[i].radius = q.radius; sp[i].surface_kind = q.surface.tag; sp[i].alpha = q.surface.alpha; sp[i].scattering = q.surface.scattering;
+        }
+        std::vector<rtmi_scene_t*> all{handle_};
+        all.insert(all.end(), extra_.begin(), extra_.end());
+        for (rtmi_scene_t* hh : all)
+            if (rtmi_scene_set_spheres(hh, sp.data(), sp.size()) != RTMI_OK) {
+                const std::string msg = std::string("rtmi_scene_set_spheres: ") + rtmi_last_error();
+                invalidate();
+                throw std::runtime_error(msg);
+            }
+    }
     rtmi_scene_get_tuning(handle_, &defaults_);
     key_scene_ = &s; key_generation_ = s.generation; key_ntris_ = s.tris.size();
     key_nboxes_ = s.boxes.boxes.size(); key_nrefs_ = s.boxes.tri_refs.size();

@@ -103,10 +103,20 @@ BoundingBox build_bounding_box_gpu(const std::vector<Triangle>& tris, const Poin
                                    size_t minobjs, int device = 0);
 BoundingBox build_trivial_bounding_box(const std::vector<Triangle>& tris, const Point& orig, float len2);  // :847-856
 
+// Analytic sphere: NOT in the reference at this revision (only Triangle is Collidable, raytrace.rs:399; make_sphere
+// tessellates).  A build-defined extension named by BASELINE's north_star; semantics in include/rtmi.h (rtmi_sphere_t)
+// and, in full, in the oracle (oracle/rt_oracle.cpp, struct Sphere).  Parity with the Rust binary: unpinned.
+struct Sphere {
+    Point center;
+    float radius;
+    SurfaceKind surface;
+};
+
 // raytrace.rs:1297-1303 (debug_ctx / debug_en: out of scope)
 struct Scene {
     std::vector<Triangle> tris;
     BoundingBox boxes;
+    std::vector<Sphere> spheres;  // analytic spheres: a flat list tested against every ray after the box tree
     // Bumped by touch(): a HipRayCaster keeps the uploaded copy of a Scene resident and re-uploads when the
     // generation it saw differs.  Code that edits tris/boxes in place must call touch() afterwards.
     uint64_t generation = 0;

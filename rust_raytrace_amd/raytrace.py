@@ -131,6 +131,11 @@ class Scene:
         """obj_data.extend(make_sphere(...)) — raytrace.rs:464-529"""
         _chk(_ffi.lib().rth_add_sphere(self.h, _p(_f(orig)), r, lat_lon[0], lat_lon[1], *surface.args(), edge_thickness))
 
+    def push_analytic_sphere(self, center, radius, surface):
+        """Analytic sphere primitive: a build-defined extension (the reference only tessellates, raytrace.rs:464-529);
+        a flat list tested against every ray after the box tree.  Semantics: include/rtmi.h (rtmi_sphere_t)."""
+        _chk(_ffi.lib().rth_add_analytic_sphere(self.h, _p(_f(center)), radius, *surface.args()))
+
     def populate_triangle_numbers(self):
         _ffi.lib().rth_populate_triangle_numbers(self.h)
 

@@ -74,6 +74,9 @@ class OracleApi:
     def add_triangle(self, s, *a):
         s.add_triangle(*a)
 
+    def add_analytic_sphere(self, s, *a):
+        s.add_analytic_sphere(*a)
+
     def transform(self, d, roll_deg):
         return self.m.create_transform(self.m.unit(d), self.m.to_radians(roll_deg))
 
@@ -109,6 +112,9 @@ class ProductApi:
 
     def add_triangle(self, s, *a):
         s.push_triangle(*a)
+
+    def add_analytic_sphere(self, s, *a):
+        s.push_analytic_sphere(*a)
 
     def transform(self, d, roll_deg):
         return self.m.create_transform(self.m.unit(d), self.m.to_radians(roll_deg))
@@ -173,6 +179,23 @@ def recipe_circles(accel="octree", maxdepth=6, minobjs=8):
             s.build_bounding_box([0.0, 0.0, 10.0], 10.0, maxdepth, minobjs)
         else:
             s.build_trivial_bounding_box([0.0, 0.0, 0.0], 20.0)
+        return s
+    return r
+
+
+def recipe_circles_analytic():
+    """BASELINE config 1 as north_star words it ("circles scene (few spheres)") with ANALYTIC spheres -- a build-defined
+    primitive the reference does not have (parity unpinned): a ground disk of triangles in a small octree plus four
+    spheres, Solid / Matte / Reflective, one of them with the camera looking through its inside."""
+    def r(api):
+        s = api.scene()
+        api.add_disk(s, [0.0, -1.5, 8.0], api.unit([0.0, 1.0, 0.05]), 6.0, 0.05, 24, api.matte((90, 140, 90), 0.3), api.solid((20, 20, 20)), -1.0)
+        s.populate_triangle_numbers()
+        s.build_bounding_box([0.0, 0.0, 10.0], 10.0, 5, 8)
+        api.add_analytic_sphere(s, [-1.6, 0.0, 7.0], 1.0, api.solid((200, 30, 30)))
+        api.add_analytic_sphere(s, [0.9, 0.2, 6.0], 0.8, api.matte((30, 60, 200), 0.4))
+        api.add_analytic_sphere(s, [2.8, 0.5, 9.0], 1.3, api.reflective(0.05, (220, 220, 220), 0.8))
+        api.add_analytic_sphere(s, [2.0, 0.0, 0.1], 1.5, api.matte((240, 200, 40), 0.15))   # contains the camera (2, 0, 0)
         return s
     return r
 

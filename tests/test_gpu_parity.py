@@ -804,3 +804,53 @@ def _bvh_other(orc, R, OracleApi, ProductApi):
     img = np.zeros((28, 40, 4), np.float32)
     R.HipRayCaster(seed=5, options=R.OPT_BVH).walk_rays(R.canonical_viewport(40, 28, 4, 3), sp, img, 1, False)
     assert_bits_equal(ref, img, "triangle soup, BVH mode")
+
+
+def test_analytic_spheres_config1_circles():
+    """a12 / BASELINE config 1 ("circles scene (few spheres), 256 x 256, 1 spp"): ANALYTIC spheres -- a build-defined
+    primitive (the reference at this revision has none: parity with the Rust binary is unpinned; the oracle states the
+    definition, tests/test_oracle_cpu.py pins it with known answers).  HIP path vs oracle, bit for bit: the plumbing
+    frame of config 1, a seeded multi-sample frame (bounces off and inside spheres, one sphere contains the camera), the
+    sphere list changing under a resident scene, explicit rays through rtmi_trace (hit index = ntris + sphere)."""
+    from conftest import recipe_circles_analytic, OracleApi, ProductApi
+    orc, R = _orc(), _R()
+    so, sp = build_pair(recipe_circles_analytic())
+    for (w, h, spp, depth, seed) in ((256, 256, 1, 5, 1), (64, 48, 5, 5, 3), (33, 17, 2, 2, 9)):
+        vo = orc.canonical_viewport(w, h)
+        vp = R.canonical_viewport(w, h, depth, spp)
+        ref, cn = so.render(w, h, vo, depth, spp, seed=seed, threads=8)
+        img = np.zeros((h, w, 4), np.float32)
+        ctx = R.HipRayCaster(seed=seed).walk_rays(vp, sp, img, 1, False)
+        assert_bits_equal(ref, img, f"analytic spheres {w}x{h}x{spp}")
+        assert ctx.total_rays == cn["rays"]
+    assert not np.array_equal(ref[..., :3], np.broadcast_to(orc.make_color(128, 180, 255), ref[..., :3].shape))  # not all sky
+    # explicit rays: spheres beat / lose against the triangles of the ground disk
+    ntris = sp.num_tris()
+    rng = np.random.default_rng(4)
+    n = 4000
+    o4 = np.zeros((n, 4), np.float32)
+    d4 = np.zeros((n, 4), np.float32)
+    o4[:, :3] = rng.uniform(-3, 3, (n, 3)) + np.array([0.5, 0.5, 5.0])
+    d = rng.normal(size=(n, 3))
+    d4[:, :3] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    tri_t, t_t, face_t, _ = so.trace(o4, d4)              # the oracle's tree (triangles only) ...
+    idx_s, t_s, face_s = so.trace_spheres(o4, d4)         # ... and its sphere list, merged by the stated rule
+    take = (idx_s != 0) & ((tri_t == 0) | (t_s < t_t))
+    exp_tri = np.where(take, ntris + idx_s - 1, tri_t).astype(np.uint32)
+    exp_t = np.where(take, t_s, t_t)
+    exp_face = np.where(take, face_s, face_t)
+    tri_g, t_g, face_g, _ = R.HipRayCaster().trace(sp, o4, d4)
+    assert np.array_equal(exp_tri, tri_g)
+    hit = exp_tri != 0
+    assert (tri_g >= ntris).sum() > 300 and ((tri_g > 0) & (tri_g < ntris)).sum() > 100
+    assert_bits_equal(exp_t[hit], t_g[hit], "hit time")
+    assert np.array_equal(exp_face[hit], face_g[hit])
+    # the sphere list can change under a resident scene (generation counter), and the BVH mode sees spheres too
+    sp.push_analytic_sphere([0.0, 0.0, 4.0], 0.5, R.SurfaceKind.Solid(R.make_color(1, 2, 3)))
+    so.add_analytic_sphere([0.0, 0.0, 4.0], 0.5, orc.Surface(orc.SOLID, orc.make_color(1, 2, 3)))
+    ref, _ = so.render(40, 40, orc.canonical_viewport(40, 40), 5, 2, seed=2, threads=8)
+    img = np.zeros((40, 40, 4), np.float32)
+    R.HipRayCaster(seed=2).walk_rays(R.canonical_viewport(40, 40, 5, 2), sp, img, 1, False)
+    assert_bits_equal(ref, img, "after adding a sphere")
+    with pytest.raises(RuntimeError):
+        sp.push_analytic_sphere([0.0, 0.0, 4.0], 0.5, R.SurfaceKind(7, R.make_color(1, 2, 3)))

@@ -135,3 +135,22 @@ def test_render_window_equals_rows():
     assert cf == cr and cw["rays"] < cr["rays"]
     with pytest.raises(RuntimeError):
         so.render_window(64, 48, vo, 5, 3, 44, 6, 0, 64)
+
+
+def test_analytic_sphere_definition_known_answers():
+    """a12: the analytic sphere is a BUILD-DEFINED primitive (the reference at this revision only tessellates spheres,
+    raytrace.rs:464-529) -- parity with the Rust binary is unpinned by construction.  These known answers pin the
+    definition itself (oracle/rt_oracle.cpp, struct Sphere): exact roots on exactly representable inputs, the inside
+    (Back-face) hit, the `t < 0` miss rule, strict-closer replacement in list order."""
+    orc = _orc()
+    s = orc.Scene(with_dummy=True)
+    m = orc.Surface(orc.SOLID, orc.make_color(10, 20, 30))
+    s.add_analytic_sphere([0.0, 0.0, 5.0], 1.0, m)
+    s.add_analytic_sphere([0.0, 0.0, 9.0], 2.0, m)
+    s.add_analytic_sphere([0.0, 0.0, 5.0], 1.0, m)      # a duplicate of sphere 1: never wins (strict <)
+    o = np.array([[0, 0, 0, 0], [0, 0, 5, 0], [0, 0, 20, 0], [3, 0, 0, 0], [0, 0, 6.5, 0], [1, 0, 0, 0]], np.float32)
+    d = np.array([[0, 0, 1, 0], [0, 0, 1, 0], [0, 0, 1, 0], [0, 0, 1, 0], [0, 0, 1, 0], [0, 0, 1, 0]], np.float32)
+    idx, t, face = s.trace_spheres(o, d)
+    assert idx.tolist() == [1, 1, 0, 0, 2, 1]            # from inside sphere 1; behind every sphere; off axis; between; tangent
+    assert t.tolist() == [4.0, 1.0, 0.0, 0.0, 0.5, 5.0]
+    assert face.tolist() == [0, 1, 0, 0, 0, 0]           # 1 = Back: the far root seen from inside
