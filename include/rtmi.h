@@ -95,8 +95,8 @@ typedef struct rtmi_tile {
 
 /* Analytic sphere.  NOT part of the reference at this revision (its only `Collidable` is `Triangle`, raytrace.rs:399;
  * spheres are tessellated by make_sphere, raytrace.rs:464-529); BASELINE's north_star names an analytic ray-sphere
- * test, so this build defines one -- parity with the Rust binary is unpinned by construction.  Semantics (the oracle's
- * `struct Sphere` states them in full): standard quadratic in the reference's Vec3 arithmetic, `t < 0` is a miss like
+ * test, so this build defines one -- parity with the Rust binary is unpinned by construction.  Semantics (DESIGN.md 4.6 states
+ * them operation by operation): standard quadratic in the reference's Vec3 arithmetic, `t < 0` is a miss like
  * for triangles, the far root counts as a Back-face hit from inside, normal = (point - center).unit(); no edge faces.
  * A scene's spheres are a flat list: every ray is tested against every sphere AFTER the box tree and a sphere replaces
  * the tree's hit iff it is strictly closer.  Reported hit index = ntris + sphere index. */

@@ -4,11 +4,11 @@
 // Triangle::intersects arithmetic (raytrace.rs:400-439, tri_test()), the lowest triangle index winning exact ties —
 // i.e. exactly what the reference itself computes for a scene whose accelerator is build_trivial_bounding_box
 // (raytrace.rs:847-856: one leaf, the list scanned in index order with strict `<`, raytrace.rs:1012-1050).  That
-// linear-list render is this mode's oracle with ONE stated exception: a "hit" whose time is +-inf or NaN is ignored.
+// linear-list render is what this mode is checked against, with ONE stated exception: a "hit" whose time is +-inf or NaN is ignored.
 // The reference accepts such hits (a ray exactly parallel to a triangle's plane, norm.dir == 0: lane 3 of
 // Vec3::mult(inf) turns NaN and every later comparison passes, raytrace.rs:402-439) wherever the triangle is, so no
-// spatial index can find them; they are artefacts (the linear-list oracle shows a few per 10^4 samples).  Tests: BVH
-// mode == the oracle's linear list with orc_set_finite_hits_only(1), bit for bit.  Against the octree traversal the
+// spatial index can find them; they are artefacts (a few per 10^4 samples of a linear-list render).  The tests compare
+// this mode with the CPU restatement of the reference's linear list with those hits switched off, bit for bit.  Against the octree traversal the
 // result can also differ where the octree's builder lost a triangle (false negative of box_contains_polygon) and
 // where two triangles tie exactly; bench.py --bvh reports the differing-pixel count.
 //

@@ -660,7 +660,7 @@ __global__ void __launch_bounds__(256) k_deinterleave(const uint8_t* __restrict_
 }
 
 // Analytic spheres (rtmi_sphere_t; a build-defined extension, see include/rtmi.h): every ray of the pass against the
-// scene's flat sphere list, after the tree's closest hit.  4-lane arithmetic exactly as the oracle's sphere_intersects.
+// scene's flat sphere list, after the tree's closest hit.  4-lane Vec3 arithmetic in the operation order DESIGN.md 4.6 states.
 __global__ void __launch_bounds__(256) k_trace_spheres(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
                                                        const DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
                                                        float* __restrict__ hit_t) {

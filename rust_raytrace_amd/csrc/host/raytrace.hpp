@@ -105,7 +105,7 @@ BoundingBox build_trivial_bounding_box(const std::vector<Triangle>& tris, const 
 
 // Analytic sphere: NOT in the reference at this revision (only Triangle is Collidable, raytrace.rs:399; make_sphere
 // tessellates).  A build-defined extension named by BASELINE's north_star; semantics in include/rtmi.h (rtmi_sphere_t)
-// and, in full, in the oracle (oracle/rt_oracle.cpp, struct Sphere).  Parity with the Rust binary: unpinned.
+// and, operation by operation, in DESIGN.md 4.6.  Parity with the Rust binary: unpinned.
 struct Sphere {
     Point center;
     float radius;
