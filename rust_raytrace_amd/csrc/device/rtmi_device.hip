@@ -1341,11 +1341,13 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
             HIPCHK(hipMemsetAsync(w.ctrl.p, 0, sizeof(DCtrl), st));
             HIPCHK(hipEventRecord(w.ev[0], st));
             hipLaunchKernelGGL(k_gen, dim3(ew_blocks), dim3(256), 0, st, dv, seed, pix0, npaths, w.qo[0].p, w.qd[0].p, w.qpath[0].p, w.ctrl.p);
+            HIPCHK(hipGetLastError());  // a refused launch is reported where it happens, not at the end of the batch
             for (uint32_t pass = 0; pass < maxdepth; pass++) {
                 const int a = pass & 1, b = a ^ 1;
                 HIPCHK(hipEventRecord(w.pass_ev[2 * pass], st));
                 if (counting) launch_trace<true>(s, w, st, w.qo[a].p, w.qd[a].p, (int)pass, w.pass_ev[2 * pass + 1]);
                 else launch_trace<false>(s, w, st, w.qo[a].p, w.qd[a].p, (int)pass, w.pass_ev[2 * pass + 1]);
+                HIPCHK(hipGetLastError());
                 if (counting && verbose) {
                     DCtrl hc2;
                     HIPCHK(hipMemcpyAsync(&hc2, w.ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost, st));
@@ -1365,6 +1367,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
                 hipLaunchKernelGGL(k_shade, dim3(ew_blocks), dim3(256), 0, st, s->d, dv, seed, pix0, npaths, (int)pass,
                                    w.qo[a].p, w.qd[a].p, w.qpath[a].p, w.hit_tf.p, w.hit_t.p, w.qo[b].p, w.qd[b].p,
                                    w.qpath[b].p, w.mstack.p, w.scol.p, w.ctrl.p);
+                HIPCHK(hipGetLastError());
                 launches++;
             }
             hipLaunchKernelGGL(k_accum, dim3(ew_blocks), dim3(256), 0, st, np, spp, w.scol.p, out, pix0, W, S, nsub, t);
