@@ -105,3 +105,30 @@ def test_gather_frame_gloo_world2(H, S):
     assert np.array_equal(frame[3, :, 1], np.arange(W, dtype=np.float32))
     owner = (np.arange(H) // S) % world
     assert np.array_equal(frame[:, 0, 2], owner.astype(np.float32))
+
+
+def test_bench_self_launches_its_ranks(monkeypatch):
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE) must start the N ranks itself -- torch.distributed.run
+    as a CHILD process, before the parent touches a GPU -- and exit with their status (round 1 raised SystemExit here,
+    which would have failed the driver's scaling run)."""
+    import importlib
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                   # the children's status is the parent's
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
