@@ -462,7 +462,8 @@ def test_two_stream_subtiles_small_and_ragged(canonical_pair):
 
 def test_fast_option_is_opt_in_and_close(canonical_pair):
     """RTMI_OPT_FAST is NOT the reference's traversal (it skips boxes behind the ray origin) and is never the default.
-    On the canonical scene it has been identical so far; allow a handful of pixels, require the same ray count order."""
+    Pinned on this frame (canonical scene, 96 x 96 @ 4 spp, seed 1): 0 differing pixels and the same ray count; at the
+    full config-3 size 17 of 4 194 304 pixels differ (include/rtmi.h)."""
     so, sp = canonical_pair
     R = _R()
     vp = R.canonical_viewport(96, 96, 5, 4)
@@ -471,8 +472,7 @@ def test_fast_option_is_opt_in_and_close(canonical_pair):
     r0 = R.HipRayCaster(seed=1).walk_rays(vp, sp, exact, 1, False).total_rays
     r1 = R.HipRayCaster(seed=1, options=R.OPT_FAST).walk_rays(vp, sp, fast, 1, False).total_rays
     differing = int((exact.view(np.uint32) != fast.view(np.uint32)).any(axis=2).sum())
-    assert differing <= 4, differing
-    assert abs(r1 - r0) <= 64
+    assert differing == 0 and r1 == r0 == 51644
     ref, _ = so.render(96, 96, _orc().canonical_viewport(96, 96), 5, 4, seed=1, threads=8)
     assert_bits_equal(ref, exact, "default mode stays exact")
 
