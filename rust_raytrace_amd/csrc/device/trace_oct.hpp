@@ -85,7 +85,10 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
     const uint32_t count = ctrl->count[pass];
     if (blockIdx.x == 0 && lane == 0) atomicAdd(&ctrl->rays, (unsigned long long)count);
     unsigned long long cnt[5] = {0, 0, 0, 0, 0};
-    unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // COUNT only: S steps, S lanes, L steps, L lanes, refills, refill lanes, edge steps, edge lanes
+    // COUNT only: S steps, S lanes, L steps, L lanes, refills, refill lanes, edge steps, edge lanes, then shader-clock
+    // cycles (s_memtime) this wave spent in SELECT steps, LEAF steps, refills, and in total
+    unsigned long long dbg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float root_half = sc.root_half;
     const uint32_t inf_bits = 0x7F800000u;
@@ -116,6 +119,7 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
         if (!exhausted && (__popcll(m_idle) >= refill_min || m_idle == ~0ull)) {
             // ---- refill: idle lanes take consecutive queued rays
             const uint32_t n = (uint32_t)__popcll(m_idle);
+            const unsigned long long t_r0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
             if (COUNT && lane == 0) { dbg[4]++; dbg[5] += n; }
             // XCD-aware work fetch: the queue is cut into 8 contiguous ranges, one per XCD (each XCD has its own
             // L2, so the waves of an XCD walk one image region and share its boxes/triangles there).  A wave pulls
@@ -144,11 +148,13 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                     mode = M_SELECT;
                 }
             }
+            if (COUNT && lane == 0) dbg[10] += __builtin_amdgcn_s_memtime() - t_r0;
             continue;
         }
         const int nS = __popcll(__ballot(mode == M_SELECT));
         const int nL = __popcll(__ballot(mode == M_LEAF));
         if (COUNT && lane == 0) { if (nS >= nL) { dbg[0]++; dbg[1] += nS; } else { dbg[2]++; dbg[3] += nL; } }
+        const unsigned long long t_s0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         if (nS >= nL) {  // majority vote; hysteresis (stay in a phase until its lanes fall below 1/2..1/8 of the other's) measured 1-7 % slower
             // ================================================= SELECT step
             if (mode == M_SELECT) {
@@ -322,13 +328,18 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                 }
             }
         }
+        if (COUNT && lane == 0) {  // the step is over for the wave when its slowest lane is (s_memtime is a scalar read)
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_s0;
+            if (nS >= nL) dbg[8] += dt; else dbg[9] += dt;
+        }
     }
     if (COUNT) {
+        if (lane == 0) dbg[11] = __builtin_amdgcn_s_memtime() - t_begin;
 #pragma unroll
         for (int k = 0; k < 5; k++)
             if (cnt[k]) atomicAdd(&ctrl->counters[k], cnt[k]);
 #pragma unroll
-        for (int k = 0; k < 8; k++)
+        for (int k = 0; k < 12; k++)
             if (dbg[k]) atomicAdd(&ctrl->dbg[k], dbg[k]);
     }
 }

@@ -22,11 +22,14 @@ lib.rth_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
 out = (C.c_ulonglong * 16)()
 lib.rth_debug_counters(scene.h, out)
 d = list(out)
-names = ["S steps", "S lanes", "L steps", "L lanes", "refills", "refill lanes", "edge blocks", "edge lanes", "scan steps", "scan lanes"]
+names = ["S steps", "S lanes", "L steps", "L lanes", "refills", "refill lanes", "edge blocks", "edge lanes", "S cycles", "L cycles", "refill cycles", "wave cycles"]
 for n, v in zip(names, d):
     print(f"{n:14s} {v}")
 rays = ctx.stats["rays"]
 print("NOTE: dbg counters cover only the LAST batch/pass sequence of the call (ctrl is reset per batch)")
 print(f"S lane util {d[1] / max(d[0] * 64, 1):.3f}   L lane util {d[3] / max(d[2] * 64, 1):.3f}   edge lanes/block {d[7] / max(d[6], 1):.2f}")
-print(f"per ray: S steps {d[1] / rays:.1f}  L (test) steps {d[3] / rays:.1f}  scan steps {d[9] / rays:.1f}  wave-steps per ray-wave: S {d[0] * 64 / rays:.1f} test {d[2] * 64 / rays:.1f} scan {d[8] * 64 / rays:.1f}")
-print(f"scan lane util {d[9] / max(d[8] * 64, 1):.3f}   tri tests {ctx.stats['tri_tests'] / rays:.1f} per ray, tested after memo {4 * d[3] / rays:.1f} slots per ray")
+print(f"per ray: S steps {d[1] / rays:.1f}  L steps {d[3] / rays:.1f}  wave-steps per ray-wave: S {d[0] * 64 / rays:.1f} L {d[2] * 64 / rays:.1f}")
+tot = max(d[11], 1)
+print(f"shader-clock cycles of a wave (counting build, all passes of the last batch): SELECT steps {d[8] / tot:.3f}, LEAF steps {d[9] / tot:.3f}, "
+      f"refills {d[10] / tot:.3f}, vote/rest {1 - (d[8] + d[9] + d[10]) / tot:.3f} of the wave's lifetime; "
+      f"{d[8] / max(d[0], 1):.0f} cycles per SELECT step, {d[9] / max(d[2], 1):.0f} per LEAF step, {d[10] / max(d[4], 1):.0f} per refill")
