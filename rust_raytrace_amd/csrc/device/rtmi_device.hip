@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <type_traits>
 #include <new>
 #include <string>
 #include <thread>

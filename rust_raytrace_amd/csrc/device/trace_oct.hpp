@@ -46,6 +46,7 @@
 //             (the sentinel triangle is never in a tree, raytrace.rs:791) or after a full block whose 4th
 //             index has bit 31 set.
 #pragma once
+#include <type_traits>
 
 namespace rtmi {
 
@@ -226,16 +227,16 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                         const uint32_t ex = (uint32_t)__builtin_amdgcn_sbfe((int)cand, o, 1);
                         tm[o] = __uint_as_float((__float_as_uint(tmv[o]) & ex) | (inf_bits & ~ex));  // a colliding tmin is never NaN and never +inf
                     }
-                    const float m1 = min3f(min3f(tm[0], tm[1], tm[2]), min3f(tm[3], tm[4], tm[5]), fminf(tm[6], tm[7]));
+                    const float m1 = min3f(min3f(tm[0], tm[1], tm[2]), min3f(tm[3], tm[4], tm[5]), min3f(tm[6], tm[7], tm[7]));
                     // Next child of the sorted order = smallest tmin among the remaining ones, lowest index on ties
                     // (the insertion sort is stable).  Skip rule raytrace.rs:965: with a hit in this box only a child
                     // with tmin < best t is entered, and since the order is ascending and the best t never grows the
                     // first child that fails ends the box.  Without a hit yet a child whose tmin == f32::MAX is not
                     // entered (raytrace.rs:986; it looks like an empty boxmap slot) -- and then neither is any later
                     // one, because every remaining tmin is >= this one.
-                    bool ok = nh != 0u;
-                    if (fw & O_HAS) ok = ok & (m1 < ft);
-                    else ok = ok & (m1 != FLT_MAX);
+                    // One compare does all of that: without a candidate m1 is +inf, with one it is in [-MAX, MAX] (a
+                    // colliding tmin is never NaN or +inf), where `!= MAX` is `< MAX`; and `inf < ft` is false for every ft.
+                    const bool ok = m1 < ((fw & O_HAS) ? ft : FLT_MAX);
                     uint32_t bit = 0u;
 #pragma unroll
                     for (int o = 7; o >= 0; o--) bit = (tm[o] == m1) ? (1u << o) : bit;
@@ -279,19 +280,20 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                 // padding index 0 reads the sentinel's record and is masked out); see tri_test() for the lane-3
                 // terms.  A reference that passes `t >= 0` and the bounding-radius test becomes the lane's pending
                 // candidate; its edge part runs below, once per step.
-                uint32_t ptri = 0u, pback = 0u;
-                float pt = 0.f, pix = 0.f, piy = 0.f, piz = 0.f, pz = 0.f;
+                uint32_t ptri = 0u;
+                float pt = 0.f, pix = 0.f, piy = 0.f, piz = 0.f, pden = 0.f;
                 auto resolve = [&]() {
                     // all four edge records are requested together and every comparison is evaluated (no
                     // short-circuit): one memory round trip instead of three
                     if (COUNT) { cnt[2]++; const unsigned long long em = __ballot(true); if (lane == __ffsll((long long)em) - 1) { dbg[6]++; dbg[7] += __popcll(em); } }
                     const float4 e0 = sc.tedge[4 * ptri], e1 = sc.tedge[4 * ptri + 1], e2 = sc.tedge[4 * ptri + 2], e3 = sc.tedge[4 * ptri + 3];
+                    const float pz = (r.dw * pt + r.ow) * 0.f;  // lane-3 product ip.w * side.w (side.w is +-0); ip.w as the plane part computed it
                     const float d0 = ((pix * e0.x + piy * e0.y) + piz * e0.z) + pz;
                     const float d1 = ((pix * e1.x + piy * e1.y) + piz * e1.z) + pz;
                     const float d2 = ((pix * e2.x + piy * e2.y) + piz * e2.z) + pz;
                     const bool inside = !(d0 > e0.w) & !(d1 > e1.w) & !(d2 > e2.w);
                     const bool edge = (d0 > e3.x) | (d1 > e3.y) | (d2 > e3.z);
-                    const uint32_t face = pback | (edge ? 2u : 0u);
+                    const uint32_t face = (pden > 0.f ? 1u : 0u) | (edge ? 2u : 0u);  // back face: norm . dir > 0
                     const bool take = inside & (!lhave | (pt < lt));  // raytrace.rs:1028-1038
                     lt = take ? pt : lt;
                     ltf = take ? (ptri | (face << 30)) : ltf;
@@ -313,8 +315,7 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                     ptri = c ? ids[k] : ptri;
                     pt = c ? t : pt;
                     pix = c ? ix : pix; piy = c ? iy : piy; piz = c ? iz : piz;
-                    pz = c ? pw * 0.f : pz;  // lane-3 product ip.w * side.w (side.w is +-0)
-                    pback = c ? (den > 0.f ? 1u : 0u) : pback;
+                    pden = c ? den : pden;
                 }
                 if (ptri != 0u) resolve();
                 if (!more) {
