@@ -953,6 +953,9 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
                 rec[1] = make_uint4(base_inner, q1y, offlo, offhi);
             }
         }
+        // k_trace_oct addresses its records with 32-bit byte offsets (ld_off32): 32 B per inner box and per triangle plane
+        // record, 64 B per triangle edge record, 16 B per reference block
+        if (ok && (ninner >= (1ull << 27) || ntris >= (1ull << 26) || hob.size() >= (1ull << 28))) { ok = false; why = "an array of the octree form would exceed 4 GiB"; }
         if (!ok) { hfn.clear(); hob.clear(); hwl.clear(); }
     }
 

@@ -76,6 +76,14 @@ __device__ inline float min3f(float a, float b, float c) {
     return d;
 }
 
+// 16-byte record at a 32-bit byte offset from a wave-uniform base: the `global_load_dwordx4 v, v_off, s[base]` form, one
+// VALU instruction for the address instead of a 64-bit shift and add (rtmi_scene_create checks that every array of the
+// octree form is smaller than 4 GiB)
+template <typename T>
+__device__ inline T ld_off32(const T* base, uint32_t byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)byte_off);
+}
+
 template <bool COUNT, bool FAST>
 __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
                                                   DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
@@ -180,8 +188,7 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                     }
                 }
                 if (mode == M_SELECT) {
-                    const uint4* fp = sc.fnodes + 2 * (size_t)fnode;
-                    const uint4 q0 = fp[0], q1 = fp[1];
+                    const uint4 q0 = ld_off32(sc.fnodes, fnode << 5), q1 = ld_off32(sc.fnodes, (fnode << 5) + 16u);
                     const float cx = __uint_as_float(q0.x), cy = __uint_as_float(q0.y), cz = __uint_as_float(q0.z);
                     const float hc = ldexpf(root_half, -(lvl + 1));  // half edge of the children (depth lvl + 1)
                     if (COUNT && (fw & 0xFFu) == 0u) { cnt[0] += __popc(q0.w & 0xFFu); cnt[3]++; }  // first visit: collides() on every child
@@ -250,7 +257,7 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                             const uint32_t oct = (uint32_t)__ffs((int)bit) - 1u;
                             if (q0.w & FN_WIDE) lblock = sc.wlinks[(size_t)q1.y * 8u + oct];  // rare: explicit indices
                             else lblock = q1.y + __builtin_amdgcn_ubfe(oct < 4u ? q1.z : q1.w, (oct & 3u) * 8u, 8u);
-                            blk = sc.oblocks[lblock];
+                            blk = ld_off32(sc.oblocks, lblock << 4);
                             lhave = false; lt = 0.f; ltf = 0;
                             if (COUNT) cnt[4]++;
                             mode = M_LEAF;
@@ -273,9 +280,9 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                 const uint32_t ids[4] = {blk.x, blk.y, blk.z, blk.w & 0x7FFFFFFFu};
                 float4 p0[4], p1[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) { p0[k] = sc.tplane[2 * ids[k]]; p1[k] = sc.tplane[2 * ids[k] + 1]; }
+                for (int k = 0; k < 4; k++) { p0[k] = ld_off32(sc.tplane, ids[k] << 5); p1[k] = ld_off32(sc.tplane, (ids[k] << 5) + 16u); }
                 const bool more = blk.w != 0u && !(blk.w >> 31);  // bit 31 of the 4th index: this full block is the last
-                if (more) { lblock++; blk = sc.oblocks[lblock]; }  // prefetch the next block
+                if (more) { lblock++; blk = ld_off32(sc.oblocks, lblock << 4); }  // prefetch the next block
                 // Triangle::intersects (raytrace.rs:400-439), plane part for the 4 references, branch-free (a
                 // padding index 0 reads the sentinel's record and is masked out); see tri_test() for the lane-3
                 // terms.  A reference that passes `t >= 0` and the bounding-radius test becomes the lane's pending
@@ -286,7 +293,8 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                     // all four edge records are requested together and every comparison is evaluated (no
                     // short-circuit): one memory round trip instead of three
                     if (COUNT) { cnt[2]++; const unsigned long long em = __ballot(true); if (lane == __ffsll((long long)em) - 1) { dbg[6]++; dbg[7] += __popcll(em); } }
-                    const float4 e0 = sc.tedge[4 * ptri], e1 = sc.tedge[4 * ptri + 1], e2 = sc.tedge[4 * ptri + 2], e3 = sc.tedge[4 * ptri + 3];
+                    const uint32_t eo = ptri << 6;
+                    const float4 e0 = ld_off32(sc.tedge, eo), e1 = ld_off32(sc.tedge, eo + 16u), e2 = ld_off32(sc.tedge, eo + 32u), e3 = ld_off32(sc.tedge, eo + 48u);
                     const float pz = (r.dw * pt + r.ow) * 0.f;  // lane-3 product ip.w * side.w (side.w is +-0); ip.w as the plane part computed it
                     const float d0 = ((pix * e0.x + piy * e0.y) + piz * e0.z) + pz;
                     const float d1 = ((pix * e1.x + piy * e1.y) + piz * e1.z) + pz;
