@@ -160,8 +160,10 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
             if (COUNT && lane == 0) dbg[10] += __builtin_amdgcn_s_memtime() - t_r0;
             continue;
         }
-        const int nS = __popcll(__ballot(mode == M_SELECT));
-        const int nL = __popcll(__ballot(mode == M_LEAF));
+        // 32-bit counts: hipcc compares two popcountll results as 64-bit values, on the VALU
+        const unsigned long long mS = __ballot(mode == M_SELECT), mL = __ballot(mode == M_LEAF);
+        const int nS = __builtin_popcount((uint32_t)mS) + __builtin_popcount((uint32_t)(mS >> 32));
+        const int nL = __builtin_popcount((uint32_t)mL) + __builtin_popcount((uint32_t)(mL >> 32));
         if (COUNT && lane == 0) { if (nS >= nL) { dbg[0]++; dbg[1] += nS; } else { dbg[2]++; dbg[3] += nL; } }
         const unsigned long long t_s0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         if (nS >= nL) {  // majority vote; hysteresis (stay in a phase until its lanes fall below 1/2..1/8 of the other's) measured 1-7 % slower
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                             if (q0.w & FN_WIDE) lblock = sc.wlinks[(size_t)q1.y * 8u + oct];  // rare: explicit indices
                             else lblock = q1.y + __builtin_amdgcn_ubfe(oct < 4u ? q1.z : q1.w, (oct & 3u) * 8u, 8u);
                             blk = ld_off32(sc.oblocks, lblock << 4);
-                            lhave = false; lt = 0.f; ltf = 0;
+                            lhave = false;  // lt, ltf are dead until the first hit of the leaf sets them
                             if (COUNT) cnt[4]++;
                             mode = M_LEAF;
                         } else {
