@@ -116,7 +116,6 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
     bool ghave = false;          // running best over the ray's leaf results
     float gt = 0.f;
     uint32_t gtf = 0;
-    uint4 blk = make_uint4(0, 0, 0, 0);  // current reference block of the leaf being scanned
     uint32_t lblock = 0;
     bool lhave = false;
     float lt = 0.f;
@@ -259,7 +258,6 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                             const uint32_t oct = (uint32_t)__ffs((int)bit) - 1u;
                             if (q0.w & FN_WIDE) lblock = sc.wlinks[(size_t)q1.y * 8u + oct];  // rare: explicit indices
                             else lblock = q1.y + __builtin_amdgcn_ubfe(oct < 4u ? q1.z : q1.w, (oct & 3u) * 8u, 8u);
-                            blk = ld_off32(sc.oblocks, lblock << 4);
                             lhave = false;  // lt, ltf are dead until the first hit of the leaf sets them
                             if (COUNT) cnt[4]++;
                             mode = M_LEAF;
@@ -279,12 +277,13 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
         } else {
             // ================================================= LEAF step: one block of <= 4 references
             if (mode == M_LEAF) {
+                const uint4 blk = ld_off32(sc.oblocks, lblock << 4);
                 const uint32_t ids[4] = {blk.x, blk.y, blk.z, blk.w & 0x7FFFFFFFu};
                 float4 p0[4], p1[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) { p0[k] = ld_off32(sc.tplane, ids[k] << 5); p1[k] = ld_off32(sc.tplane, (ids[k] << 5) + 16u); }
                 const bool more = blk.w != 0u && !(blk.w >> 31);  // bit 31 of the 4th index: this full block is the last
-                if (more) { lblock++; blk = ld_off32(sc.oblocks, lblock << 4); }  // prefetch the next block
+                if (more) lblock++;
                 // Triangle::intersects (raytrace.rs:400-439), plane part for the 4 references, branch-free (a
                 // padding index 0 reads the sentinel's record and is masked out); see tri_test() for the lane-3
                 // terms.  A reference that passes `t >= 0` and the bounding-radius test becomes the lane's pending
