@@ -169,13 +169,7 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
             // ================================================= SELECT step
             if (mode == M_SELECT) {
                 // pop finished frames; the frames of depth 0 .. lvl-1 are in LDS levels 0 .. lvl-1
-                while (fw & O_DONE) {
-                    if (lvl == 0) {
-                        hit_tf[ridx] = ghave ? gtf : 0u;
-                        hit_t[ridx] = ghave ? gt : 0.f;
-                        mode = M_IDLE;
-                        break;
-                    }
+                while ((fw & O_DONE) && lvl != 0) {
                     const bool have = (fw & O_HAS) != 0;
                     const float ct = ft;
                     lvl--;
@@ -188,7 +182,11 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                         fw |= O_HAS;
                     }
                 }
-                if (mode == M_SELECT) {
+                if (fw & O_DONE) {  // the root frame is finished: the ray is
+                    hit_tf[ridx] = ghave ? gtf : 0u;
+                    hit_t[ridx] = ghave ? gt : 0.f;
+                    mode = M_IDLE;
+                } else {
                     const uint4 q0 = ld_off32(sc.fnodes, fnode << 5), q1 = ld_off32(sc.fnodes, (fnode << 5) + 16u);
                     const float cx = __uint_as_float(q0.x), cy = __uint_as_float(q0.y), cz = __uint_as_float(q0.z);
                     const float hc = ldexpf(root_half, -(lvl + 1));  // half edge of the children (depth lvl + 1)
