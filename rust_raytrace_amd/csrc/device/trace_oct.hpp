@@ -143,8 +143,7 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                 if (base < hi) break;
                 if (++tries == nranges) { exhausted = true; break; }
             }
-            if (exhausted) continue;
-            if (mode == M_IDLE) {
+            if (!exhausted && mode == M_IDLE) {
                 const uint32_t i = base + (uint32_t)__popcll(m_idle & lt_mask);
                 if (i < hi) {
                     ridx = i;
@@ -157,7 +156,7 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                 }
             }
             if (COUNT && lane == 0) dbg[10] += __builtin_amdgcn_s_memtime() - t_r0;
-            continue;
+            // no `continue`: the step below runs in the same iteration (one back edge, fewer copies of the loop-carried state)
         }
         // 32-bit counts: hipcc compares two popcountll results as 64-bit values, on the VALU
         const unsigned long long mS = __ballot(mode == M_SELECT), mL = __ballot(mode == M_LEAF);
