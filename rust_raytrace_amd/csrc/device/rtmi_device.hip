@@ -954,8 +954,8 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
             }
         }
         // k_trace_oct addresses its records with 32-bit byte offsets (ld_off32): 32 B per inner box and per triangle plane
-        // record, 64 B per triangle edge record, 16 B per reference block
-        if (ok && (ninner >= (1ull << 27) || ntris >= (1ull << 26) || hob.size() >= (1ull << 28))) { ok = false; why = "an array of the octree form would exceed 4 GiB"; }
+        // record, 64 B per triangle edge record, 16 B per reference block; its stack keeps an inner box's record index in 22 bits
+        if (ok && (ninner >= (1ull << 22) || ntris >= (1ull << 26) || hob.size() >= (1ull << 28))) { ok = false; why = "more than 2^22 inner boxes, or an array of the octree form would exceed 4 GiB"; }
         if (!ok) { hfn.clear(); hob.clear(); hwl.clear(); }
     }
 
@@ -1043,12 +1043,14 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
                   s->octree ? s->fnodes.p : nullptr, s->octree ? s->oblocks.p : nullptr, s->octree ? s->wlinks.p : nullptr, nullptr, 0u, boxes[0].len2, max_inner_depth + 1};
     s->hmats = hm;
     if (s->octree) {
-        s->oct_lds = (size_t)std::max<uint32_t>(1u, max_inner_depth) * 12 * 64;  // 3 words per level per lane
+        s->oct_lds = (size_t)std::max<uint32_t>(1u, max_inner_depth) * 8 * 64;  // 2 words per level per lane
         if (s->oct_lds > 64 * 1024) { s->octree = false; s->why_generic = "octree deeper than the LDS stack allows"; }
         else {
             int nb = 0;
+            // 16 waves per CU (4 per SIMD) unless less fits: the kernel is bound by VALU issue, more resident waves only add
+            // cache pressure (12 / 14 / 16 / 17 / 18 / 20 / 24 waves: 929 / 962 / 980 / 985 / 971 / 965 / 955 Mrays/s)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_oct<false, false>, 64, s->oct_lds) == hipSuccess && nb > 0)
-                s->oct_blocks_per_cu = nb;
+                s->oct_blocks_per_cu = std::min(nb, 16);
             // ray-pool form: 24 state words + 2 per stack level, an odd number of 16-B quads per slot (conflict-free
             // ds_read_b128 of neighbouring slots); as many rays as fit 1/8 of the CU's 160 KB (8 waves per CU)
             uint32_t quads = (24u + 2u * std::max<uint32_t>(1u, max_inner_depth) + 3u) / 4u;

@@ -85,7 +85,7 @@ __device__ inline T ld_off32(const T* base, uint32_t byte_off) {
 }
 
 template <bool COUNT, bool FAST>
-__global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
+__global__ void __launch_bounds__(64, 4) k_trace_oct(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
                                                   DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
                                                   float* __restrict__ hit_t, int refill_min, int xcd_aware) {
     extern __shared__ uint32_t lds[];
@@ -176,10 +176,10 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                     const bool have = (fw & O_HAS) != 0;
                     const float ct = ft;
                     lvl--;
-                    const uint32_t* fr = lds + lvl * 3 * NT + lane;
-                    fnode = fr[0];
-                    fw = fr[NT];
-                    ft = __uint_as_float(fr[2 * NT]);
+                    const uint32_t* fr = lds + lvl * 2 * NT + lane;
+                    fnode = fr[0] & 0x3FFFFFu;
+                    fw = fr[0] >> 22;
+                    ft = __uint_as_float(fr[NT]);
                     if (have) {  // fold step of raytrace.rs:949-1007: first hit is taken, later ones replace iff strictly closer
                         if (!(fw & O_HAS) || ct < ft) ft = ct;
                         fw |= O_HAS;
@@ -263,10 +263,9 @@ __global__ void __launch_bounds__(64, 5) k_trace_oct(DScene sc, const float4* __
                             if (COUNT) cnt[4]++;
                             mode = M_LEAF;
                         } else {
-                            uint32_t* fr = lds + lvl * 3 * NT + lane;
-                            fr[0] = fnode;
-                            fr[NT] = fw;
-                            fr[2 * NT] = __float_as_uint(ft);
+                            uint32_t* fr = lds + lvl * 2 * NT + lane;
+                            fr[0] = fnode | (fw << 22);  // record index (< 2^22, checked at scene creation) | visited bits, DONE, HAS
+                            fr[NT] = __float_as_uint(ft);
                             lvl++;
                             // record of this inner child: the inner children before it in octant order
                             fnode = q1.x + (uint32_t)__popc((q0.w & ~leafmask & 0xFFu) & (bit - 1u));
