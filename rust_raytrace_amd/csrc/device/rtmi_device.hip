@@ -780,7 +780,8 @@ struct rtmi_scene {
     bool root_is_leaf = false; // build_trivial_bounding_box: one list for every ray -> k_trace_linear
     bool octree = false;       // the tree passed the exact-octree check
     std::string why_generic;   // reason when it did not
-    int oct_blocks_per_cu = 8;
+    int oct_blocks_per_cu = 8;   // what fits (occupancy query)
+    uint32_t active_streams = 1; // sub-tiles of the render call in flight: their persistent kernels share the CUs
     size_t oct_lds = 0;
     // k_trace_pool: rays per wave, slot stride (words), LDS bytes per wave, waves per CU; pool_P == 0: not available
     uint32_t pool_P = 0, pool_stride = 0;
@@ -1047,10 +1048,8 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
         if (s->oct_lds > 64 * 1024) { s->octree = false; s->why_generic = "octree deeper than the LDS stack allows"; }
         else {
             int nb = 0;
-            // 16 waves per CU (4 per SIMD) unless less fits: the kernel is bound by VALU issue, more resident waves only add
-            // cache pressure (12 / 14 / 16 / 17 / 18 / 20 / 24 waves: 929 / 962 / 980 / 985 / 971 / 965 / 955 Mrays/s)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_oct<false, false>, 64, s->oct_lds) == hipSuccess && nb > 0)
-                s->oct_blocks_per_cu = std::min(nb, 16);
+                s->oct_blocks_per_cu = nb;
             // ray-pool form: 24 state words + 2 per stack level, an odd number of 16-B quads per slot (conflict-free
             // ds_read_b128 of neighbouring slots); as many rays as fit 1/8 of the CU's 160 KB (8 waves per CU)
             uint32_t quads = (24u + 2u * std::max<uint32_t>(1u, max_inner_depth) + 3u) / 4u;
@@ -1199,7 +1198,12 @@ static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* q
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_linear<COUNT>), dim3((unsigned)(s->num_cu * 8)), dim3(256), 0, st, s->d, qo, qd,
                            w.ctrl.p, pass, w.hit_tf.p, w.hit_t.p);
     } else if (s->octree && !(s->options & RTMI_OPT_GENERIC)) {
-        const int per_cu = s->tune.oct_waves_per_cu ? (int)s->tune.oct_waves_per_cu : s->oct_blocks_per_cu;
+        // About 24 resident waves per CU in all is the optimum of this VALU-issue-bound kernel (more only adds cache
+        // pressure): one stream launches what fits, two or more share the CUs with 16 each (two streams: 12 / 14 / 16 / 17 /
+        // 18 / 20 / 24 waves per launch = 929 / 962 / 980 / 985 / 971 / 965 / 955 Mrays/s; one stream: 16 / 20 / 24 = 808 /
+        // 882 / 931).
+        const int per_cu = s->tune.oct_waves_per_cu ? (int)s->tune.oct_waves_per_cu
+                                                     : s->active_streams > 1 ? std::min(s->oct_blocks_per_cu, 16) : s->oct_blocks_per_cu;
         const dim3 grid((unsigned)(s->num_cu * per_cu)), block(64);
         const int refill = (int)(pass == 0 ? s->tune.refill_min0 : s->tune.refill_min);
         const int xcd = (int)(s->tune.xcd_aware % 3u);  // 1 = ranges by XCC_ID, 2 = by blockIdx % 8, 0 = one range
@@ -1297,6 +1301,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     uint32_t nsub = std::min<uint32_t>(std::max<uint32_t>(s->tune.streams, 1u), (uint32_t)RTMI_MAX_STREAMS);
     nsub = std::min<uint32_t>(nsub, nstripes);
     if (npix * spp < s->tune.subtile_min_paths) nsub = 1;
+    s->active_streams = nsub;
     SubTile sub[RTMI_MAX_STREAMS];
     for (uint32_t t = 0; t < nsub; t++) {
         DView& dv = sub[t].dv;
@@ -1526,6 +1531,7 @@ int rtmi_trace(rtmi_scene_t* s, uint64_t n, const float* orig4, const float* dir
     HIPCHK(hipMemsetAsync(w.ctrl.p, 0, sizeof(DCtrl), st));
     hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, w.ctrl.p, (uint32_t)n);
     HIPCHK(hipEventRecord(w.ev[0], st));
+    s->active_streams = 1;
     if (s->options & RTMI_OPT_COUNTERS) launch_trace<true>(s, w, st, w.qo[0].p, w.qd[0].p, 0, w.ev[1]);
     else launch_trace<false>(s, w, st, w.qo[0].p, w.qd[0].p, 0, w.ev[1]);
     HIPCHK(hipGetLastError());
