@@ -301,7 +301,7 @@ def roofline_object(args, caster, scene, vp, tile, local, stream, rays_per_frame
     frame_ms = kernel_ms / args.steps                          # device time span of one frame in the timed region
     chip = flops / (frame_ms * 1e-3) / 1e12
     # Per-launch duration of the dominant kernel, measured live with HIP events on its launch stream.  In the timed
-    # region two sub-tiles run on two streams and their launches share the GPU, which stretches every launch; so the
+    # region the sub-tiles run on their own streams and their launches share the GPU, which stretches every launch; so the
     # kernel is also run ALONE here: one frame on a single internal stream (tuning streams = 1), one launch per pass.
     from rust_raytrace_amd import raytrace as R2
     solo = R2.HipRayCaster(seed=caster.seed, device=caster.device, options=base_opts, tuning={"streams": 1})
@@ -311,7 +311,7 @@ def roofline_object(args, caster, scene, vp, tile, local, stream, rays_per_frame
     avg_launch_ms = sctx.stats["trace_ms"] / n_launch_frame
     solo_frame_ms = sctx.stats["kernel_ms"]
     achieved = flops / n_launch_frame / (avg_launch_ms * 1e-3) / 1e12
-    shared_launch_ms = trace_ms / max(launches, 1)             # the same per launch in the timed region (two streams)
+    shared_launch_ms = trace_ms / max(launches, 1)             # the same per launch in the timed region (several streams)
     # measured fabric traffic and VALU issue rate: from the committed rocprofv3 --pmc passes of this config (a profile
     # is a separate run: rocprofv3 cannot run inside bench.py); null when the workload is not the profiled one
     prof = None
@@ -359,7 +359,7 @@ def roofline_object(args, caster, scene, vp, tile, local, stream, rays_per_frame
         "note": "achieved = algorithmic FP32 flops of ONE closest-hit launch (device counters of a counting pass / launches per frame) / "
                 "its average HIP-event duration with the kernel alone on the GPU (one internal stream; this is what rocprofv3 "
                 "--kernel-trace of RTMI_STREAMS=1 reports, profiles/); peak = 157.3/2 TFLOP/s because a*b+c may not be contracted "
-                "(bit parity).  The timed region runs two sub-tiles on two streams whose launches overlap: chip_frame prices a frame's "
+                "(bit parity).  The timed region runs the sub-tiles on their own streams, whose launches overlap: chip_frame prices a frame's "
                 "flops against the frame's device time there.",
     }
 

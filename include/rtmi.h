@@ -153,8 +153,8 @@ int rtmi_scene_set_options(rtmi_scene_t* scene, uint32_t options);
  * here.  None of them changes a pixel: any batch size, stream count or stripe split gives the same image. */
 typedef struct rtmi_tuning {
     uint64_t batch_paths;       /* paths (pixel samples) per batch of the wavefront pipeline; default 256 Mi  */
-    uint32_t streams;           /* 1..4 internal HIP streams (interleaved sub-tiles of a tile); default 2        */
-    uint32_t subtile_min_paths; /* tiles with fewer paths are not split over two streams; default 32768       */
+    uint32_t streams;           /* 1..4 internal HIP streams (interleaved sub-tiles of a tile); default 3        */
+    uint32_t subtile_min_paths; /* tiles with fewer paths are not split over streams; default 32768           */
     uint32_t oct_waves_per_cu;  /* persistent waves per CU of the octree kernel; 0 = occupancy query          */
     uint32_t refill_min0;       /* idle lanes before a wave refills, primary pass (64 = whole wave); default 64 */
     uint32_t refill_min;        /* the same for bounce passes; default 8                                       */

@@ -1000,7 +1000,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     rtmi_scene* s = own.s;
     s->device = device;
     s->tune.batch_paths = env_size("RTMI_BATCH_PATHS", (size_t)256 << 20);
-    s->tune.streams = (uint32_t)std::min<size_t>(env_size("RTMI_STREAMS", 2), RTMI_MAX_STREAMS);
+    s->tune.streams = (uint32_t)std::min<size_t>(env_size("RTMI_STREAMS", 3), RTMI_MAX_STREAMS);
     s->tune.subtile_min_paths = (uint32_t)std::min<size_t>(env_size("RTMI_SUBTILE_MIN_PATHS", 32768), 0xFFFFFFFFu);
     s->tune.oct_waves_per_cu = (uint32_t)std::min<size_t>(env_size("RTMI_OCT_WAVES_PER_CU", 0), 32);
     s->tune.refill_min0 = (uint32_t)std::min<size_t>(env_size("RTMI_REFILL_MIN0", 64), 64);
@@ -1293,12 +1293,12 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
 
     // ---- the caller's tile as stripes (a contiguous band is cut into <= 16-row stripes), split over the streams
     uint32_t S = tile->stripe_rows, step = tile->stripe_step;
-    if ((uint64_t)S >= nrows) {  // one stripe = contiguous band
-        S = std::min<uint32_t>(16u, std::max<uint32_t>(1u, (nrows + 1) / 2));
+    uint32_t nsub = std::min<uint32_t>(std::max<uint32_t>(s->tune.streams, 1u), (uint32_t)RTMI_MAX_STREAMS);
+    if ((uint64_t)S >= nrows) {  // one stripe = contiguous band: at least one stripe per stream
+        S = std::min<uint32_t>(16u, std::max<uint32_t>(1u, (nrows + nsub - 1) / nsub));
         step = S;
     }
     const uint32_t nstripes = (nrows + S - 1) / S;
-    uint32_t nsub = std::min<uint32_t>(std::max<uint32_t>(s->tune.streams, 1u), (uint32_t)RTMI_MAX_STREAMS);
     nsub = std::min<uint32_t>(nsub, nstripes);
     if (npix * spp < s->tune.subtile_min_paths) nsub = 1;
     s->active_streams = nsub;

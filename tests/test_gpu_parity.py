@@ -431,8 +431,8 @@ def test_odd_sizes_and_many_samples(circles_pair):
 
 
 def test_two_stream_subtiles_small_and_ragged(canonical_pair):
-    """The library splits a tile into two interleaved sub-tiles on two internal streams.  Force that on small,
-    odd-sized images (partial last stripe, contiguous bands, striped tiles) and compare with the one-stream result."""
+    """The library splits a tile into interleaved sub-tiles on 2 or 3 (the default) internal streams.  Force that on
+    small, odd-sized images (partial last stripe, contiguous bands, striped tiles) and compare with the one-stream result."""
     import torch
     from rust_raytrace_amd import dist as rd
     so, sp = canonical_pair
@@ -441,19 +441,21 @@ def test_two_stream_subtiles_small_and_ragged(canonical_pair):
         vo = orc.canonical_viewport(w, h)
         vp = R.canonical_viewport(w, h, 5, spp)
         ref, cn = so.render(w, h, vo, 5, spp, seed=4, threads=8)
-        two = {"subtile_min_paths": 1}
-        img = np.zeros((h, w, 4), np.float32)
-        ctx = R.HipRayCaster(seed=4, tuning=two).walk_rays(vp, sp, img, 1, False)
-        assert ctx.stats["streams"] == (2 if h >= 2 else 1)
-        assert_bits_equal(ref, img, f"two streams {w}x{h}")
-        assert ctx.total_rays == cn["rays"]
-        # a striped tile (rank 1 of 3, 4-row stripes) with both streams
-        tile = rd.rank_tile(1, 3, h, 4)
-        if tile[1]:
-            buf = torch.zeros((tile[1], w, 4), dtype=torch.float32, device="cuda:0")
-            R.HipRayCaster(seed=4, tuning=two).walk_tile_device(vp, sp, tile, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
-            torch.cuda.synchronize()
-            assert_bits_equal(ref[rd.tile_rows(tile, h)], buf.cpu().numpy(), f"striped two streams {w}x{h}")
+        for k in (2, 3):
+            multi = {"subtile_min_paths": 1, "streams": k}
+            img = np.zeros((h, w, 4), np.float32)
+            ctx = R.HipRayCaster(seed=4, tuning=multi).walk_rays(vp, sp, img, 1, False)
+            stripe = min(16, max(1, -(-h // k)))   # a contiguous band is cut into at least one stripe per stream
+            assert ctx.stats["streams"] == min(k, -(-h // stripe))
+            assert_bits_equal(ref, img, f"{k} streams {w}x{h}")
+            assert ctx.total_rays == cn["rays"]
+            # a striped tile (rank 1 of 3, 4-row stripes) on the same streams
+            tile = rd.rank_tile(1, 3, h, 4)
+            if tile[1]:
+                buf = torch.zeros((tile[1], w, 4), dtype=torch.float32, device="cuda:0")
+                R.HipRayCaster(seed=4, tuning=multi).walk_tile_device(vp, sp, tile, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                assert_bits_equal(ref[rd.tile_rows(tile, h)], buf.cpu().numpy(), f"striped, {k} streams {w}x{h}")
         one = np.zeros((h, w, 4), np.float32)
         ctx1 = R.HipRayCaster(seed=4, tuning={"subtile_min_paths": 1, "streams": 1}).walk_rays(vp, sp, one, 1, False)
         assert ctx1.stats["streams"] == 1
