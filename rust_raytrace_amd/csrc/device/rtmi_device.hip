@@ -1322,6 +1322,12 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     uint64_t pix_per_batch = std::max<uint64_t>(1, want_paths / spp);
     uint64_t max_sub_npix = 0;
     for (uint32_t t = 0; t < nsub; t++) max_sub_npix = std::max(max_sub_npix, sub[t].npix);
+    // equal batches: a sub-tile a little larger than the budget (thirds of a frame whose stripes do not divide evenly)
+    // would otherwise get a full batch and a sliver with five tiny passes of its own
+    if (pix_per_batch < max_sub_npix) {
+        const uint64_t nb = (max_sub_npix + pix_per_batch - 1) / pix_per_batch;
+        pix_per_batch = max_sub_npix * 8 <= pix_per_batch * 9 ? max_sub_npix : (max_sub_npix + nb - 1) / nb;
+    }
     pix_per_batch = std::min<uint64_t>(pix_per_batch, max_sub_npix);
     if (pix_per_batch * spp >= (1ull << 31)) return fail(RTMI_ERR_UNSUPPORTED, "batch above 2^31 paths");
     for (uint32_t t = 0; t < nsub; t++) {
