@@ -152,10 +152,12 @@ int rtmi_scene_set_options(rtmi_scene_t* scene, uint32_t options);
  * RTMI_REFILL_MIN, RTMI_XCD_AWARE, RTMI_KERNEL; RTMI_VERBOSE=1 prints per-pass timings to stderr) and can be read and changed
  * here.  None of them changes a pixel: any batch size, stream count or stripe split gives the same image. */
 typedef struct rtmi_tuning {
-    uint64_t batch_paths;       /* paths (pixel samples) per batch of the wavefront pipeline; default 256 Mi  */
+    uint64_t batch_paths;       /* paths (pixel samples) per batch of the wavefront pipeline, all streams together; default 256 Mi.
+                                   A tile up to 1/8 larger is still rendered as one batch.                    */
     uint32_t streams;           /* 1..4 internal HIP streams (interleaved sub-tiles of a tile); default 3        */
     uint32_t subtile_min_paths; /* tiles with fewer paths are not split over streams; default 32768           */
-    uint32_t oct_waves_per_cu;  /* persistent waves per CU of the octree kernel; 0 = occupancy query          */
+    uint32_t oct_waves_per_cu;  /* persistent waves per CU and launch of the octree kernel; 0 = automatic: what
+                                   fits with one stream, at most 16 when several streams share the CUs       */
     uint32_t refill_min0;       /* idle lanes before a wave refills, primary pass (64 = whole wave); default 64 */
     uint32_t refill_min;        /* the same for bounce passes; default 8                                       */
     uint32_t xcd_aware;         /* 1 = one ray-queue range per XCD (by XCC_ID), 2 = by block index, 0 = one queue */
