@@ -1,4 +1,6 @@
 """-m gpu: the HIP path (through the C ABI) against the CPU oracle, bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -332,7 +334,10 @@ def test_render_grid_config5_reduced():
         assert ctx.stats[k] == cn[k], k
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+_SOUP_SEEDS = [1, 2, 3, 4] + [int(x) for x in os.environ.get("RTMI_TEST_EXTRA_SOUP_SEEDS", "").split(",") if x]
+
+
+@pytest.mark.parametrize("seed", _SOUP_SEEDS)
 def test_random_triangle_soups(seed):
     """Random scenes: triangle soup with random surfaces and edge thickness, random octree parameters and camera.
     Exercises boxes with many colliding children, leaves of all sizes, deep and shallow trees."""
@@ -364,10 +369,11 @@ def test_random_triangle_soups(seed):
     so, sp = recipe(OracleApi(orc)), recipe(ProductApi(R))
     assert so.num_tris() == sp.num_tris()
     pos = rng.uniform(-1, 1, 3).astype(np.float32)
-    direction = orc.unit([float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)), 1.0])
+    aim = [float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)), 1.0]
+    assert_bits_equal(orc.unit(aim), R.unit(aim), "unit")
     w, h, spp, depth = 40, 28, int(rng.integers(1, 5)), int(rng.integers(1, 7))
-    vo = orc.create_viewport(w, h, (1.0, 0.7), pos, direction, 75.0, 0.1)
-    vp = R.create_viewport((w, h), (1.0, 0.7), pos, R.unit(direction), 75.0, 0.1, depth, spp)
+    vo = orc.create_viewport(w, h, (1.0, 0.7), pos, orc.unit(aim), 75.0, 0.1)
+    vp = R.create_viewport((w, h), (1.0, 0.7), pos, R.unit(aim), 75.0, 0.1, depth, spp)  # unit() once on either side
     assert_bits_equal(vo, vp.vp12, "viewport")
     ref, cn = so.render(w, h, vo, depth, spp, seed=seed, threads=8)
     img = np.zeros((h, w, 4), np.float32)
@@ -375,6 +381,11 @@ def test_random_triangle_soups(seed):
     assert_bits_equal(ref, img, f"image (ntri {ntri}, octree ({maxdepth},{minobjs}), spp {spp}, depth {depth})")
     for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
         assert ctx.stats[k] == cn[k], k
+    # the kernels without the counting code are separate instantiations: the same image from them too
+    img2 = np.zeros((h, w, 4), np.float32)
+    ctx2 = R.HipRayCaster(seed=seed).walk_rays(vp, sp, img2, 1, False)
+    assert_bits_equal(ref, img2, f"image, plain build (ntri {ntri}, octree ({maxdepth},{minobjs}), spp {spp}, depth {depth})")
+    assert ctx2.total_rays == cn["rays"]
 
 
 def test_quantize_device_matches_oracle(canonical_pair):
