@@ -27,7 +27,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
-#include <type_traits>
 #include <new>
 #include <string>
 #include <thread>

@@ -12,14 +12,15 @@
 //  * a lane is in one of two working states, SELECT (at an inner box: pop
 //    finished frames, pick the next child) or LEAF (scan one 16-B block of
 //    triangle references).  Each iteration the wave runs the step that the
-//    majority of its lanes wait for, instead of serialising nested loops;
+//    majority of its lanes wait for (weighted 3 : 2 towards SELECT, whose
+//    step is the cheaper one), instead of serialising nested loops;
 //  * LAZY CHILD SELECTION instead of a sort.  The reference sorts the <= 8
 //    colliding children by tmin (stable insertion sort, raytrace.rs:941-947)
 //    and folds over them.  Visiting "the smallest tmin not visited yet, lowest
 //    index on ties" one child at a time is the same order, and a ray enters
 //    only ~1.4 children of a box on average, so the kernel never sorts: every
 //    SELECT step recomputes the 8 implicit child slabs of the current box
-//    (6 plane pairs + 8 max3/min3, nothing loaded but the box's own 64-B
+//    (6 plane pairs + 8 max3/min3, nothing loaded but the box's own 32-B
 //    record), masks out absent and already visited children, takes the
 //    minimum and applies the skip rule to it.  Half the VALU work of the
 //    previous sort-then-recheck form (rank sort 105 + recheck 25 per child);
@@ -31,8 +32,14 @@
 //    is needed by ~4 % of the plane tests.  It is DEFERRED: the plane tests of
 //    a block run branch-free for all lanes, a lane remembers its candidate and
 //    the edge part runs once per step for all lanes that have one;
-//  * the stack of frames lives in LDS, [level][word][lane]: a lane only ever
-//    touches its own bank.
+//  * the stack of frames lives in LDS, [level][word][lane], 2 words per frame
+//    (record index | flags << 22, best t): a lane only ever touches its own
+//    bank;
+//  * nothing but the ray, the current frame, the running best and the leaf
+//    cursor is carried from step to step, and the loop has ONE back edge:
+//    hipcc copies every loop-carried register that is written inside nested
+//    divergent branches into a temporary and back ("the
+//    instruction diet").
 //
 // Records (HBM, served from L2 / Infinity Cache):
 //   fnodes  : 2 x uint4 (32 B) per INNER box: (cx, cy, cz, present mask | leaf mask << 8 | FN_WIDE)
@@ -46,7 +53,6 @@
 //             (the sentinel triangle is never in a tree, raytrace.rs:791) or after a full block whose 4th
 //             index has bit 31 set.
 #pragma once
-#include <type_traits>
 
 namespace rtmi {
 
