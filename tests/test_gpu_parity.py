@@ -388,6 +388,35 @@ def test_random_triangle_soups(seed):
     assert ctx2.total_rays == cn["rays"]
 
 
+_CAMERA_SEEDS = [1, 2, 3] + [int(x) for x in os.environ.get("RTMI_TEST_EXTRA_CAMERA_SEEDS", "").split(",") if x]
+
+
+@pytest.mark.parametrize("seed", _CAMERA_SEEDS)
+def test_random_cameras_canonical_scene(canonical_pair, seed):
+    """The canonical scene from random viewpoints, inside and outside the teapot and the root box, looking anywhere:
+    primary rays then also start in the middle of the tree (boxes behind the origin, rays leaving the root box at once,
+    grazing directions) -- what only bounce rays do from the fixed camera."""
+    so, sp = canonical_pair
+    orc, R = _orc(), _R()
+    rng = np.random.default_rng(7000 + seed)
+    pos = (rng.uniform(-6, 6, 3) + np.array([0, 0, 5.0])).astype(np.float32) if seed % 3 else rng.uniform(-30, 30, 3).astype(np.float32)
+    aim = [float(x) for x in rng.normal(size=3)]
+    w, h, spp, depth = 36, 26, int(rng.integers(1, 4)), int(rng.integers(1, 6))
+    fov, roll = float(rng.uniform(30, 120)), float(rng.uniform(-1, 1))
+    vo = orc.create_viewport(w, h, (1.0, 0.7), pos, orc.unit(aim), fov, roll)
+    vp = R.create_viewport((w, h), (1.0, 0.7), pos, R.unit(aim), fov, roll, depth, spp)
+    assert_bits_equal(vo, vp.vp12, "viewport")
+    ref, cn = so.render(w, h, vo, depth, spp, seed=seed, threads=8)
+    for opts in (0, R.OPT_COUNTERS):
+        img = np.zeros((h, w, 4), np.float32)
+        ctx = R.HipRayCaster(seed=seed, options=opts, tuning={"subtile_min_paths": 1}).walk_rays(vp, sp, img, 1, False)
+        assert_bits_equal(ref, img, f"camera {pos} -> {aim}, spp {spp}, depth {depth}, options {opts}")
+        assert ctx.total_rays == cn["rays"]
+        if opts:
+            for k in ("box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
+                assert ctx.stats[k] == cn[k], k
+
+
 def test_quantize_device_matches_oracle(canonical_pair):
     import torch
     R = _R()
