@@ -99,7 +99,7 @@ class Scene:
         self.h = C.c_void_p(_ffi.lib().rth_scene_new(1 if with_dummy else 0))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and _ffi is not None:  # module globals are None while the interpreter shuts down
             _ffi.lib().rth_scene_free(self.h)
             self.h = None
 
