@@ -82,6 +82,15 @@ typedef struct rtmi_stats {
     double trace_ms;   /* sum of the durations of the closest-hit launches (HIP events on their streams)  */
     uint32_t trace_launches;
     uint32_t streams;  /* internal streams that ran concurrently (1..4): launches overlap when > 1       */
+    /* rtmi_render_frame_multi only (0 elsewhere): host wall-clock milliseconds of this scene's steps, so that a slow
+     * link or a refused peer mapping is visible per device instead of only in the frame time */
+    double render_ms;       /* rtmi_render_tile_device of this scene's tile                                  */
+    double band_copy_ms;    /* (quantise +) the band's one crossing to the root device, synchronised           */
+    double deinterleave_ms; /* scenes[0] only: k_deinterleave (+ the copy to out_host)                         */
+    int32_t peer_access;    /* 1 = this device writes the root device's memory directly (peer access enabled, or the
+                             * same device); 0 = the runtime refused: the band is staged (rtmi_last_error() carries a
+                             * warning although the call returns RTMI_OK)                                      */
+    uint32_t reserved;
 } rtmi_stats_t;
 
 /* A set of image rows: `nrows` rows taken in stripes of `stripe_rows`
@@ -99,7 +108,12 @@ typedef struct rtmi_tile {
  * them operation by operation): standard quadratic in the reference's Vec3 arithmetic, `t < 0` is a miss like
  * for triangles, the far root counts as a Back-face hit from inside, normal = (point - center).unit(); no edge faces.
  * A scene's spheres are a flat list: every ray is tested against every sphere AFTER the box tree and a sphere replaces
- * the tree's hit iff it is strictly closer.  Reported hit index = ntris + sphere index. */
+ * the tree's hit iff it is strictly closer.  Reported hit index = ntris + sphere index.
+ * Intended, not an oversight: there is no origin-primitive exclusion and no epsilon, exactly as for the reference's
+ * triangles (`t < 0` is the only rejection, raytrace.rs:402-405; bounce origins are moved 0.001 along the NEW direction's
+ * random part, raytrace.rs:284-296, which can leave them a rounding error inside the surface).  A bounce ray whose
+ * rounded origin lies just inside its sphere therefore re-hits it from inside at t ~ 0 (Back face), as a reference
+ * bounce ray can re-hit the plane of the triangle it left; Matte/Reflective spheres are darker for it. */
 typedef struct rtmi_sphere {
     float center[3];
     float radius;
@@ -149,7 +163,7 @@ int rtmi_scene_set_options(rtmi_scene_t* scene, uint32_t options);
 
 /* Launch tuning of one scene handle.  Defaults are taken ONCE, at rtmi_scene_create(), from the environment
  * (RTMI_BATCH_PATHS, RTMI_STREAMS, RTMI_SUBTILE_MIN_PATHS, RTMI_OCT_WAVES_PER_CU, RTMI_REFILL_MIN0,
- * RTMI_REFILL_MIN, RTMI_XCD_AWARE, RTMI_KERNEL; RTMI_VERBOSE=1 prints per-pass timings to stderr) and can be read and changed
+ * RTMI_REFILL_MIN, RTMI_XCD_AWARE, RTMI_KERNEL, RTMI_PIPELINE; RTMI_VERBOSE=1 prints per-pass timings to stderr) and can be read and changed
  * here.  None of them changes a pixel: any batch size, stream count or stripe split gives the same image. */
 typedef struct rtmi_tuning {
     uint64_t batch_paths;       /* paths (pixel samples) per batch of the wavefront pipeline, all streams together; default 256 Mi.
@@ -163,6 +177,11 @@ typedef struct rtmi_tuning {
     uint32_t xcd_aware;         /* 1 = one ray-queue range per XCD (by XCC_ID), 2 = by block index, 0 = one queue */
     uint32_t kernel;            /* octree closest-hit kernel: 0 = automatic, 1 = one ray per lane (k_trace_oct),
                                  * 2 = per-wave ray pool in LDS (k_trace_pool; falls back to 1 for very deep trees) */
+    uint32_t pipeline;          /* 0 = automatic, 1 = one launch per bounce pass (k_gen, then k_trace* + k_shade per pass),
+                                 * 2 = fused path kernels: primary rays generated, traced and shaded in one kernel, all
+                                 * bounces in ONE persistent kernel that shades in place (octree scenes; anything else
+                                 * falls back to 1).  Environment: RTMI_PIPELINE.                                    */
+    uint32_t reserved;
 } rtmi_tuning_t;
 int rtmi_scene_get_tuning(rtmi_scene_t* scene, rtmi_tuning_t* out);
 int rtmi_scene_set_tuning(rtmi_scene_t* scene, const rtmi_tuning_t* in);
@@ -175,9 +194,9 @@ int rtmi_scene_set_tuning(rtmi_scene_t* scene, const rtmi_tuning_t* in);
  * rtmi_render writes host memory; rtmi_render_device writes device memory on
  * `hip_stream` (a hipStream_t, or NULL for the default stream) and returns
  * after the work is enqueued and the counters are read back. */
-/* Internally a tile is rendered as two interleaved sub-tiles on two HIP streams of the library (the small deep bounce
- * passes of one overlap the bulk of the other); they start after the work already queued on `hip_stream` and that
- * stream is made to wait for them. */
+/* Internally a tile is rendered as rtmi_tuning_t.streams (default 3) interleaved sub-tiles, each on its own HIP stream
+ * of the library (the tail of one sub-tile's persistent kernels overlaps the bulk of another's); they start after the
+ * work already queued on `hip_stream` and that stream is made to wait for them. */
 int rtmi_render(rtmi_scene_t* scene, const rtmi_viewport_t* vp, uint64_t seed,
                 uint32_t row0, uint32_t nrows, float* out_host, rtmi_stats_t* stats);
 int rtmi_render_device(rtmi_scene_t* scene, const rtmi_viewport_t* vp, uint64_t seed,

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -35,6 +36,10 @@
 
 #include "../../../include/rtmi.h"
 #include "vec4.hpp"
+
+// layouts the language bindings mirror (rust_raytrace_amd/_ffi.py, INTEGRATION.md ffi.rs; tests/test_host_cpu.py)
+static_assert(sizeof(rtmi_stats_t) == 104 && sizeof(rtmi_tuning_t) == 48 && sizeof(rtmi_tile_t) == 16 && sizeof(rtmi_box_t) == 32 &&
+              sizeof(rtmi_triangle_t) == 104 && sizeof(rtmi_viewport_t) == 64 && sizeof(rtmi_sphere_t) == 40, "ABI struct layout changed");
 
 namespace rtmi {
 
@@ -795,6 +800,9 @@ struct rtmi_scene {
     DevBuf<uint8_t> qbytes;
     DevBuf<uint8_t> mstage, mframe;  // rtmi_render_frame_multi, root scene: received bands / the frame
     hipStream_t mstream = nullptr;   // rtmi_render_frame_multi: this scene's band stream
+    int peer_root = -1;              // root device the peer-access state below refers to (-1: not asked yet)
+    int peer_ok = 0;                 // 1 = this device reaches peer_root directly (enabled once), 0 = the runtime refused
+    std::string peer_msg;            // the runtime's reason when it refused
     int num_cu = 256;
     int trace_block = 256;
     size_t trace_lds = 0;
@@ -1006,6 +1014,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     s->tune.refill_min = (uint32_t)std::min<size_t>(env_size("RTMI_REFILL_MIN", 8), 64);
     s->tune.xcd_aware = (uint32_t)(env_size("RTMI_XCD_AWARE", 1) % 3);
     s->tune.kernel = (uint32_t)std::min<size_t>(env_size("RTMI_KERNEL", 0), 2);
+    s->tune.pipeline = (uint32_t)std::min<size_t>(env_size("RTMI_PIPELINE", 0), 2);
     s->verbose = getenv("RTMI_VERBOSE") != nullptr;
     s->trace_block = block;
     s->trace_lds = (size_t)levels * 16 * block;
@@ -1155,7 +1164,7 @@ int rtmi_scene_get_tuning(rtmi_scene_t* s, rtmi_tuning_t* out) {
 int rtmi_scene_set_tuning(rtmi_scene_t* s, const rtmi_tuning_t* in) {
     if (!s || !in) return fail(RTMI_ERR_INVALID, "NULL argument");
     if (in->batch_paths == 0 || in->streams < 1 || in->streams > RTMI_MAX_STREAMS || in->oct_waves_per_cu > 32 || in->refill_min0 < 1 ||
-        in->refill_min0 > 64 || in->refill_min < 1 || in->refill_min > 64 || in->xcd_aware > 2 || in->kernel > 2)
+        in->refill_min0 > 64 || in->refill_min < 1 || in->refill_min > 64 || in->xcd_aware > 2 || in->kernel > 2 || in->pipeline > 2)
         return fail(RTMI_ERR_INVALID, "tuning value out of range");
     s->tune = *in;
     return RTMI_OK;
@@ -1267,6 +1276,10 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     const uint32_t row0 = tile->row0, nrows = tile->nrows;
     if (stats) memset(stats, 0, sizeof(*stats));
     if (nrows == 0) return RTMI_OK;
+    RTMI_GUARD_BEGIN
+    // leftovers of the caller's own HIP calls on this thread (or of failures this library tolerated, e.g. an occupancy
+    // query) must not make a launch below look refused: hipGetLastError() reports the last error of ANY runtime call
+    (void)hipGetLastError();
     if (!out_device) return fail(RTMI_ERR_INVALID, "NULL argument");
     if (vp->width == 0 || vp->height == 0) return fail(RTMI_ERR_INVALID, "empty viewport");
     if (tile->stripe_rows == 0) return fail(RTMI_ERR_INVALID, "stripe_rows must be >= 1");
@@ -1422,6 +1435,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     HIPCHK(hipEventElapsedTime(&kernel_ms, s->fork_ev, s->end_ev));
     if (stats) { stats->kernel_ms = kernel_ms; stats->trace_ms = trace_ms; stats->trace_launches = launches; stats->streams = nsub; }
     return RTMI_OK;
+    RTMI_GUARD_END
 }
 
 int rtmi_render(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t seed, uint32_t row0, uint32_t nrows,
@@ -1435,6 +1449,35 @@ int rtmi_render(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t seed, uint3
     int rc = rtmi_render_device(s, vp, seed, row0, nrows, s->tile.p, nullptr, stats);
     if (rc != RTMI_OK) return rc;
     HIPCHK(hipMemcpy(out_host, s->tile.p, npix * sizeof(float4), hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+// Direct (xGMI) access from the scene's device to `root`, asked for ONCE per (device, root) pair and remembered on the
+// handle: hipDeviceEnablePeerAccess answers hipErrorPeerAccessAlreadyEnabled from the second call on and leaves that
+// error pending for the thread's next hipGetLastError() poll (the launch checks of rtmi_render_tile_device).  Whatever the
+// answer, the pending error is cleared here; a refusal is recorded (peer_ok = 0, peer_msg) -- hipMemcpyPeerAsync still
+// works then, staged by the runtime, and rtmi_render_frame_multi reports it instead of running slowly in silence.
+static hipError_t ensure_peer_access(rtmi_scene* sc, int root) {
+    if (sc->peer_root == root) return hipSuccess;
+    sc->peer_root = root;
+    sc->peer_msg.clear();
+    if (sc->device == root) { sc->peer_ok = 1; return hipSuccess; }
+    const hipError_t pe = hipDeviceEnablePeerAccess(root, 0);
+    (void)hipGetLastError();
+    sc->peer_ok = (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) ? 1 : 0;
+    if (!sc->peer_ok) sc->peer_msg = hipGetErrorString(pe);
+    return hipSuccess;
+}
+
+// Development/test aid (not in rtmi.h): run the peer-access step for `scene` against `root_device` again, as a second
+// frame would, and report what is pending afterwards (0 = nothing).  forget != 0 drops the cached answer first.
+int rtmi_debug_peer_access(rtmi_scene_t* s, int root_device, int forget, int* peer_ok, int* pending_error) {
+    if (!s) return fail(RTMI_ERR_INVALID, "scene is NULL");
+    HIPCHK(hipSetDevice(s->device));
+    if (forget) s->peer_root = -1;
+    HIPCHK(ensure_peer_access(s, root_device));
+    if (peer_ok) *peer_ok = s->peer_ok;
+    if (pending_error) *pending_error = (int)hipGetLastError();
     return RTMI_OK;
 }
 
@@ -1469,25 +1512,28 @@ int rtmi_render_frame_multi(rtmi_scene_t* const* scenes, uint32_t nscenes, const
     std::vector<int> rcs(n, RTMI_OK);
     std::vector<std::string> errs(n);
     std::vector<rtmi_stats_t> sts(n);
-    auto work = [&](uint32_t i) {
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    auto work_body = [&](uint32_t i) {
         rtmi_scene* sc = scenes[i];
         rtmi_stats_t& st = sts[i];
-        memset(&st, 0, sizeof(st));
         auto bail = [&](int rc, const std::string& msg) { rcs[i] = rc; errs[i] = msg; };
-        if (rows[i] == 0) return;
         hipError_t e = hipSetDevice(sc->device);
-        if (e == hipSuccess && sc->device != root->device) {  // direct xGMI copies to the root instead of staging through the host
-            const hipError_t pe = hipDeviceEnablePeerAccess(root->device, 0);
-            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();  // copies still work, slower
-        }
+        if (e == hipSuccess) e = ensure_peer_access(sc, root->device);  // once per (device, root) pair, cached on the handle
+        const int peer = sc->peer_ok;
+        if (rows[i] == 0) { st.peer_access = peer; return; }
         if (e == hipSuccess && !sc->mstream) e = hipStreamCreateWithFlags(&sc->mstream, hipStreamNonBlocking);
         if (e == hipSuccess) e = sc->tile.ensure((size_t)rows[i] * W);
         if (e == hipSuccess && rgb8) e = sc->qbytes.ensure((size_t)rows[i] * W * 3);
         if (e != hipSuccess) return bail(hip_code(e), std::string("rtmi_render_frame_multi: ") + hipGetErrorString(e));
         const rtmi_tile_t tile{i * S, rows[i], S, n * S};
+        const clk::time_point t0 = clk::now();
         int rc = rtmi_render_tile_device(sc, vp, seed, &tile, sc->tile.p, sc->mstream, &st);
         if (rc != RTMI_OK) return bail(rc, g_err);
+        st.render_ms = ms_since(t0);
+        st.peer_access = peer;
         const void* band = sc->tile.p;
+        const clk::time_point t1 = clk::now();
         if (rgb8) {
             hipLaunchKernelGGL(k_quantize, dim3((unsigned)(sc->num_cu * 8)), dim3(256), 0, sc->mstream, (uint64_t)rows[i] * W,
                                (const float4*)sc->tile.p, sc->qbytes.p);
@@ -1497,23 +1543,42 @@ int rtmi_render_frame_multi(rtmi_scene_t* const* scenes, uint32_t nscenes, const
         e = hipMemcpyPeerAsync(root->mstage.p + (size_t)i * mr * W * px, root->device, band, sc->device, (size_t)rows[i] * W * px, sc->mstream);
         if (e == hipSuccess) e = hipStreamSynchronize(sc->mstream);
         if (e != hipSuccess) return bail(hip_code(e), std::string("rtmi_render_frame_multi: band copy: ") + hipGetErrorString(e));
+        st.band_copy_ms = ms_since(t1);
+    };
+    // no C++ exception leaves a worker thread (std::terminate) or crosses the ABI
+    auto work = [&](uint32_t i) {
+        memset(&sts[i], 0, sizeof(rtmi_stats_t));
+        try { work_body(i); }
+        catch (const std::bad_alloc&) { rcs[i] = RTMI_ERR_OOM; try { errs[i] = "host allocation failed"; } catch (...) {} }
+        catch (...) { rcs[i] = RTMI_ERR_INVALID; try { errs[i] = "internal error"; } catch (...) {} }
     };
     if (n == 1) work(0);
     else {
-        std::vector<std::thread> th;
-        for (uint32_t i = 0; i < n; i++) th.emplace_back(work, i);
-        for (auto& t : th) t.join();
+        struct Joiner {  // joins what was started, also when starting a later thread throws
+            std::vector<std::thread> th;
+            ~Joiner() { for (auto& t : th) if (t.joinable()) t.join(); }
+        } pool;
+        pool.th.reserve(n);
+        for (uint32_t i = 0; i < n; i++) pool.th.emplace_back(work, i);
     }
-    for (uint32_t i = 0; i < n; i++)
+    std::string warn;
+    for (uint32_t i = 0; i < n; i++) {
         if (rcs[i] != RTMI_OK) return fail(rcs[i], "scene " + std::to_string(i) + ": " + errs[i]);
+        if (!scenes[i]->peer_ok && warn.empty())
+            warn = "warning: device " + std::to_string(scenes[i]->device) + " has no peer access to root device " + std::to_string(root->device) +
+                   " (" + scenes[i]->peer_msg + "): its band is staged by the runtime, see rtmi_stats_t.peer_access / band_copy_ms";
+    }
     // ---- root: de-interleave the stripes into the frame
     HIPCHK(hipSetDevice(root->device));
     if (!root->mstream) HIPCHK(hipStreamCreateWithFlags(&root->mstream, hipStreamNonBlocking));
+    const clk::time_point t2 = clk::now();
     hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)(root->num_cu * 8)), dim3(256), 0, root->mstream, root->mstage.p, frame, W, H, S, n, mr, px);
     HIPCHK(hipGetLastError());
     if (out_host) HIPCHK(hipMemcpyAsync(out_host, frame, (size_t)H * W * px, hipMemcpyDeviceToHost, root->mstream));
     HIPCHK(hipStreamSynchronize(root->mstream));
+    sts[0].deinterleave_ms = ms_since(t2);
     if (stats) memcpy(stats, sts.data(), sizeof(rtmi_stats_t) * n);
+    g_err = warn;  // RTMI_OK with a non-empty rtmi_last_error(): the frame is right, a link is slow
     return RTMI_OK;
     RTMI_GUARD_END
 }

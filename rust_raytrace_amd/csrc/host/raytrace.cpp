@@ -565,7 +565,13 @@ void HipRayCaster::apply_settings() {
     rtmi_scene_set_options(handle_, options_);
     for (rtmi_scene_t* h : extra_) rtmi_scene_set_options(h, options_);
     rtmi_tuning_t t = defaults_;  // what rtmi_scene_create chose (environment or built-in)
-    if (!has_tuning_) { rtmi_scene_set_tuning(handle_, &t); return; }
+    // every handle of a multi-device caster gets the same tuning (and the same reset to the defaults)
+    auto set_all = [&](const rtmi_tuning_t& tt) {
+        if (rtmi_scene_set_tuning(handle_, &tt) != RTMI_OK) throw std::runtime_error(std::string("rtmi_scene_set_tuning: ") + rtmi_last_error());
+        for (rtmi_scene_t* h : extra_)
+            if (rtmi_scene_set_tuning(h, &tt) != RTMI_OK) throw std::runtime_error(std::string("rtmi_scene_set_tuning: ") + rtmi_last_error());
+    };
+    if (!has_tuning_) { set_all(t); return; }
     // 0 = keep the library default (xcd_aware, where 0 is a value, is passed as given + 1)
     if (tuning_.batch_paths) t.batch_paths = tuning_.batch_paths;
     if (tuning_.streams) t.streams = tuning_.streams;
@@ -575,7 +581,8 @@ void HipRayCaster::apply_settings() {
     if (tuning_.refill_min) t.refill_min = tuning_.refill_min;
     if (tuning_.xcd_aware) t.xcd_aware = tuning_.xcd_aware - 1;
     if (tuning_.kernel) t.kernel = tuning_.kernel;
-    if (rtmi_scene_set_tuning(handle_, &t) != RTMI_OK) throw std::runtime_error(std::string("rtmi_scene_set_tuning: ") + rtmi_last_error());
+    if (tuning_.pipeline) t.pipeline = tuning_.pipeline;
+    set_all(t);
 }
 
 rtmi_scene_t* HipRayCaster::resident(const Scene& s) {
@@ -666,11 +673,16 @@ void HipRayCaster::walk_frame_multi(const Viewport& v, const Scene& s, void* dat
     const int rc = rtmi_render_frame_multi(hs.data(), (uint32_t)hs.size(), &av, seed, stripe_rows, flags, data_host, data_device, st.data());
     if (rc != RTMI_OK) throw std::runtime_error(std::string("rtmi_render_frame_multi: ") + rtmi_last_error());
     rtmi_stats_t sum{};
+    sum.peer_access = 1;  // 1 only when every device reaches the root directly
     for (const rtmi_stats_t& d : st) {
+        if (!d.peer_access) sum.peer_access = 0;
         sum.rays += d.rays; sum.box_tests += d.box_tests; sum.tri_tests += d.tri_tests; sum.full_tests += d.full_tests;
         sum.nodes += d.nodes; sum.leaves += d.leaves; sum.trace_ms += d.trace_ms; sum.trace_launches += d.trace_launches;
         sum.kernel_ms = std::max(sum.kernel_ms, d.kernel_ms);  // the devices run concurrently
         sum.streams = std::max(sum.streams, d.streams);
+        sum.render_ms = std::max(sum.render_ms, d.render_ms);
+        sum.band_copy_ms = std::max(sum.band_copy_ms, d.band_copy_ms);
+        sum.deinterleave_ms += d.deinterleave_ms;
     }
     progress.total_rays += sum.rays;
     progress.kernel_seconds += sum.kernel_ms * 1e-3;

@@ -9,7 +9,7 @@ from conftest import OracleApi, assert_bits_equal, recipe_axis_box, recipe_circl
 
 pytestmark = pytest.mark.gpu
 
-RTMI_OK, RTMI_ERR_INVALID, RTMI_ERR_NO_DEVICE, RTMI_ERR_UNSUPPORTED = 0, 1, 2, 3
+RTMI_OK, RTMI_ERR_INVALID, RTMI_ERR_NO_DEVICE, RTMI_ERR_UNSUPPORTED, RTMI_ERR_OOM, RTMI_ERR_DEVICE = 0, 1, 2, 3, 4, 5
 
 
 class Tri(C.Structure):
@@ -259,14 +259,22 @@ def test_render_frame_multi_raw_abi():
     whole, st1 = _render(L, ffi, hs[0], vp12, w, hgt, 5, spp, seed)
     assert_bits_equal(ref, whole, "single-device render vs oracle")
     vp = Vp(w, hgt, (C.c_float * 3)(*vp12[0:3]), (C.c_float * 3)(*vp12[3:6]), (C.c_float * 3)(*vp12[6:9]), (C.c_float * 3)(*vp12[9:12]), 5, spp)
-    for n, S in ((1, 0), (3, 4), (2, 16), (3, 1)):
+    # (3, 32): stripes of 32 rows on a 45-row image -> scene 0 gets 32 rows, scene 1 gets 13, scene 2 gets NONE
+    for n, S in ((1, 0), (3, 4), (2, 16), (3, 1), (3, 32)):
         arr = (C.c_void_p * n)(*[h.value for h in hs[:n]])
         out = np.zeros((hgt, w, 4), np.float32)
         sts = (ffi.Stats * n)()
         rc = L.rtmi_render_frame_multi(arr, n, C.byref(vp), seed, S, 0, out.ctypes.data_as(C.c_void_p), None, sts)
         assert rc == RTMI_OK, L.rtmi_last_error()
+        assert L.rtmi_last_error() == b"", "no warning: every handle sits on the root device"
         assert_bits_equal(whole, out, f"multi n={n} S={S}")
         assert sum(s.rays for s in sts) == st1.rays == cn["rays"]
+        # per-device diagnostics: which scene rendered / copied for how long, and whether it reaches the root directly
+        assert all(s.peer_access == 1 for s in sts)
+        assert sts[0].deinterleave_ms > 0 and all(s.deinterleave_ms == 0 for s in sts[1:])
+        for i, s_ in enumerate(sts):
+            has_rows = (n, S, i) != (3, 32, 2)
+            assert (s_.rays > 0) == has_rows and (s_.render_ms > 0) == has_rows and (s_.band_copy_ms > 0) == has_rows
         q = np.zeros((hgt, w, 3), np.uint8)
         rc = L.rtmi_render_frame_multi(arr, n, C.byref(vp), seed, S, 1, q.ctypes.data_as(C.c_void_p), None, None)
         assert rc == RTMI_OK, L.rtmi_last_error()
@@ -279,4 +287,69 @@ def test_render_frame_multi_raw_abi():
     assert L.rtmi_render_frame_multi(arr, 1, C.byref(vp), seed, 4, 0, None, None, None) == RTMI_ERR_INVALID
     assert L.rtmi_render_frame_multi(arr, 1, C.byref(vp), seed, 4, 8, out.ctypes.data_as(C.c_void_p), None, None) == RTMI_ERR_INVALID
     for h in hs:
+        L.rtmi_scene_destroy(h)
+
+
+def test_peer_access_is_asked_once_and_leaves_nothing_pending():
+    """rtmi_render_frame_multi used to call hipDeviceEnablePeerAccess on every frame; from the second
+    frame on it answers hipErrorPeerAccessAlreadyEnabled and leaves that error pending for the next hipGetLastError()
+    poll of the launch checks.  The step now runs once per (device, root) pair, is cached on the handle and clears what it
+    leaves.  A one-GPU box cannot take the cross-device branch for real, so the step is driven through its test hook:
+    against the own device, against it again, after forgetting the cached answer, and against a device that does not
+    exist (a refusal: recorded, not an error, nothing pending) -- and a frame renders bit-equal right after each."""
+    from oracle import orc
+    L, ffi = _lib()
+    L.rtmi_debug_peer_access.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    so = recipe_circles()(OracleApi(orc))
+    tris, geo, topo, refs = _abi_arrays(so)
+    rc, h = _create(L, tris, _boxes(geo, topo), refs)
+    assert rc == RTMI_OK
+    try:
+        vp12 = orc.canonical_viewport(24, 20)
+        ref, _ = so.render(24, 20, vp12, 5, 2, seed=4, threads=4)
+        for root, forget, want_ok in ((0, 0, 1), (0, 0, 1), (0, 1, 1), (99, 1, 0), (99, 0, 0), (0, 1, 1)):
+            ok, pending = C.c_int(-1), C.c_int(-1)
+            assert L.rtmi_debug_peer_access(h, root, forget, C.byref(ok), C.byref(pending)) == RTMI_OK, L.rtmi_last_error()
+            assert ok.value == want_ok and pending.value == 0, (root, forget, ok.value, pending.value)
+            img, _ = _render(L, ffi, h, vp12, 24, 20, 5, 2, 4)
+            assert_bits_equal(ref, img, f"render after the peer step (root {root})")
+    finally:
+        L.rtmi_scene_destroy(h)
+
+
+def test_oom_and_device_error_codes():
+    """RTMI_ERR_OOM and RTMI_ERR_DEVICE, provoked: an allocation no MI355X can satisfy (2^36 pixels x 16 B = 1 TiB; the
+    request fails before anything is read or written), and a HIP stream handle that has already been destroyed (the HIP
+    runtime rejects it at the first enqueue).  Both leave the scene usable."""
+    from oracle import orc
+    import torch
+    L, ffi = _lib()
+    L.rtmi_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.rtmi_render_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    so = recipe_circles()(OracleApi(orc))
+    tris, geo, topo, refs = _abi_arrays(so)
+    rc, h = _create(L, tris, _boxes(geo, topo), refs)
+    assert rc == RTMI_OK
+    try:
+        small = np.zeros(16, np.float32)
+        assert L.rtmi_quantize(h, small.ctypes.data_as(C.c_void_p), 1 << 36, small.ctypes.data_as(C.c_void_p)) == RTMI_ERR_OOM
+        assert b"memory" in L.rtmi_last_error().lower()
+        # a stream created and destroyed through the process's HIP runtime (the one torch loaded)
+        hip = C.CDLL("libamdhip64.so.7")  # already mapped (torch's): dlopen by SONAME returns the same runtime
+        hip.hipStreamCreate.argtypes = [C.c_void_p]
+        hip.hipStreamDestroy.argtypes = [C.c_void_p]
+        stale = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(stale)) == 0
+        assert hip.hipStreamDestroy(stale) == 0
+        w, hgt = 16, 8
+        vp12 = orc.canonical_viewport(w, hgt)
+        vp = Vp(w, hgt, (C.c_float * 3)(*vp12[0:3]), (C.c_float * 3)(*vp12[3:6]), (C.c_float * 3)(*vp12[6:9]), (C.c_float * 3)(*vp12[9:12]), 5, 2)
+        dev = torch.zeros((hgt, w, 4), dtype=torch.float32, device="cuda:0")
+        rc = L.rtmi_render_device(h, C.byref(vp), 1, 0, hgt, C.c_void_p(dev.data_ptr()), stale, None)
+        assert rc == RTMI_ERR_DEVICE, (rc, L.rtmi_last_error())
+        # the handle still renders, and equals the oracle
+        ref, _ = so.render(w, hgt, vp12, 5, 2, seed=1, threads=4)
+        img, _ = _render(L, ffi, h, vp12, w, hgt, 5, 2, 1)
+        assert_bits_equal(ref, img, "render after the provoked errors")
+    finally:
         L.rtmi_scene_destroy(h)

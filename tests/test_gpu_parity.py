@@ -153,6 +153,38 @@ def test_render_linear_list_config2_small(generic):
     assert cn["tri_tests"] == 6720 * cn["rays"]
 
 
+def test_full_size_config2_rows_vs_oracle():
+    """BASELINE config 2 at its STATED size: teapot.obj, trivial bounding box (build_trivial_bounding_box,
+    raytrace.rs:847-856: one list of 6 720 triangles scanned in order, raytrace.rs:1012-1050), 512 x 512 @ 16 spp, depth 5,
+    seed 1.  Four rows of the frame -- sky, teapot lid, teapot body + mirror disks, below the teapot -- image bits and
+    all six work counters against the oracle (k_trace_linear, the LDS-streamed list kernel)."""
+    import os
+    orc, R = _orc(), _R()
+    so, sp = build_pair(recipe_canonical(accel="trivial", obj=TEAPOT))
+    W = H = 512
+    vo = orc.canonical_viewport(W, H)
+    vp = R.canonical_viewport(W, H, 5, 16)
+    threads = max(1, len(os.sched_getaffinity(0)))
+    c = R.HipRayCaster(seed=1, options=R.OPT_COUNTERS)
+    bounced = 0
+    for row in (3, 180, 256, 340):
+        ref, cn = so.render(W, H, vo, 5, 16, seed=1, row0=row, nrows=1, threads=threads)
+        got = np.zeros((1, W, 4), np.float32)
+        ctx = c.walk_rows(vp, sp, row, 1, got)
+        assert_bits_equal(ref, got, f"config 2 row {row}")
+        for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
+            assert ctx.stats[k] == cn[k], (row, k)
+        assert cn["tri_tests"] == 6720 * cn["rays"]
+        bounced += cn["rays"] - W * 16
+    assert bounced > 0
+    # the whole frame through the default (uncounted) kernel reproduces those rows
+    img = np.zeros((H, W, 4), np.float32)
+    R.HipRayCaster(seed=1).walk_rays(vp, sp, img, 1, False)
+    for row in (3, 256):
+        ref, _ = so.render(W, H, vo, 5, 16, seed=1, row0=row, nrows=1, threads=threads)
+        assert_bits_equal(ref[0], img[row], f"config 2 whole frame, row {row}")
+
+
 def test_trace_linear_list_edge_rays():
     # the axis-aligned scene as ONE list: NaN / inf hit times and exact ties through k_trace_linear
     from conftest import OracleApi, ProductApi
@@ -607,25 +639,30 @@ def test_full_size_config4_tiles_reproduce_frame(canonical_pair):
     assert torch.equal(frame.view(torch.int32), whole.view(torch.int32))
 
 
-def test_full_size_config5_grid_rows_vs_oracle():
+@pytest.fixture(scope="module")
+def grid_pair_gpu_built():
+    """BASELINE config 5 scene: the oracle's copy with the ORACLE's octree builder (about 10 s), the product's copy with
+    the octree built on the GPU (rtmi_builder_filter / k_box_contains), which is what bench.py renders from."""
+    from conftest import OracleApi, TEAPOT_TRI
+    so = recipe_grid()(OracleApi(_orc()))
+    sp = _R().grid_scene(TEAPOT_TRI, gpu_build=0)
+    return so, sp
+
+
+def test_full_size_config5_grid_rows_vs_oracle(grid_pair_gpu_built):
     """BASELINE config 5 at its stated octree (maxdepth 10, minobjs 19; 8 x teapot_tri.obj = 50 561 triangles,
-    ~1.6 M boxes, depth-10 LDS stack) and size (2048 x 2048 @ 64 spp): the tree is built by the product's builder
-    (bit-equal to the oracle's on CPU: tests/test_host_cpu.py) and handed to the oracle with orc_set_tree, so the
-    single-threaded oracle builder is not needed.  Sampled rows, image bits and all six work counters."""
+    988 380 boxes, depth-10 LDS stack) and size (2048 x 2048 @ 64 spp).  The product renders from the GPU-BUILT tree
+    (what bench.py uses), the oracle from the tree of its own builder (raytrace.rs:790-845): sampled rows, image bits
+    and all six work counters."""
     import os
-    from conftest import OracleApi, ProductApi, TEAPOT_TRI
     orc, R = _orc(), _R()
+    so, sp = grid_pair_gpu_built
     threads = max(1, len(os.sched_getaffinity(0)))
-    sp = R.grid_scene(TEAPOT_TRI, threads=threads)
-    # the same triangles on the oracle side, no tree build there
-    so = recipe_grid_no_tree()(OracleApi(orc))
     assert so.num_tris() == sp.num_tris() == 8 * 6320 + 1
     ro, _, _ = so.triangles()
     rp, _, _ = sp.triangles()
     assert_bits_equal(ro, rp, "triangle records")
-    geo, topo, refs = sp.tree()
-    assert int(topo[:, 3].max()) == 10
-    so.set_tree(geo, topo, refs)
+    assert int(sp.tree()[1][:, 3].max()) == 10
     W = H = 2048
     vo = orc.canonical_viewport(W, H)
     vp = R.canonical_viewport(W, H, 5, 64)
@@ -678,6 +715,14 @@ def test_caster_multi_device_fanout_in_library(canonical_pair):
     assert_bits_equal(ref, img, "two handles on one device")
     assert ctx.total_rays == cn["rays"]
     assert len(ctx.per_device) == 2 and all(d["rays"] > 0 for d in ctx.per_device)
+    assert all(d["peer_access"] == 1 and d["render_ms"] > 0 for d in ctx.per_device)
+    # tuning reaches EVERY handle of a multi-device caster (it used to stop at device 0), and so does the reset
+    big = R.canonical_viewport(256, 192, 5, spp)  # enough paths per handle for sub-tiles (subtile_min_paths)
+    bimg = np.zeros((192, 256, 4), np.float32)
+    c1 = R.HipRayCaster(seed=12, devices=[0, 0], tuning={"streams": 1}).walk_rays(big, sp, bimg, 1, False)
+    assert [d["streams"] for d in c1.per_device] == [1, 1]
+    c3 = R.HipRayCaster(seed=12, devices=[0, 0]).walk_rays(big, sp, bimg, 1, False)
+    assert [d["streams"] for d in c3.per_device] == [3, 3]
     q = np.zeros((h, w, 3), np.uint8)
     R.HipRayCaster(seed=12, devices=[0, 0]).walk_frame_multi(vp, sp, q, rgb8=True, stripe_rows=8)
     assert np.array_equal(q.reshape(-1, 3), orc.quantize(ref))
@@ -690,37 +735,41 @@ def test_caster_multi_device_fanout_in_library(canonical_pair):
 
 
 @pytest.mark.parametrize("which", ["canonical", "grid"])
-def test_octree_build_on_gpu_equals_host_build(which):
+def test_octree_build_on_gpu_equals_oracle_build(which, canonical_pair, grid_pair_gpu_built):
     """f2: build_bounding_box (raytrace.rs:790-845) with every level's box_contains_polygon tests (raytrace.rs:753-779) on
-    the GPU (rtmi_builder_filter / k_box_contains).  The flattened tree -- box geometry, topology, leaf lists -- equals the
-    host builder's bit for bit at the stated octree (10, 19), for the canonical scene and the 8-teapot grid (config 5);
-    the host builder equals the oracle's (tests/test_host_cpu.py)."""
+    the GPU (rtmi_builder_filter / k_box_contains).  The flattened tree -- box geometry, topology, leaf lists -- is compared
+    DIRECTLY with the tree of the oracle's builder (orc.Scene.tree_flatten), bit for bit, at the stated octree (10, 19), for
+    the canonical scene and the 8-teapot grid (config 5); and with the product's host builder, whose time is printed."""
     import os
     import time
     from conftest import TEAPOT_TRI
     R = _R()
     threads = max(1, len(os.sched_getaffinity(0)))
     mk = R.canonical_scene if which == "canonical" else R.grid_scene
+    so = canonical_pair[0] if which == "canonical" else grid_pair_gpu_built[0]
     t0 = time.time()
     host = mk(TEAPOT_TRI, threads=threads)
     t1 = time.time()
     gpu = mk(TEAPOT_TRI, gpu_build=0)
     t2 = time.time()
+    go, to, ro = so.tree_flatten()
     gh, th, rh = host.tree()
     gg, tg, rg = gpu.tree()
-    assert gh.shape == gg.shape and th.shape == tg.shape and rh.shape == rg.shape
-    assert_bits_equal(gh, gg, "box geometry")
-    assert np.array_equal(th, tg), "topology"
-    assert np.array_equal(rh, rg), "leaf lists"
+    assert go.shape == gg.shape and to.shape == tg.shape and ro.shape == rg.shape
+    assert_bits_equal(go, gg, "box geometry, GPU build vs oracle build")
+    assert np.array_equal(to, tg), "topology, GPU build vs oracle build"
+    assert np.array_equal(ro, rg), "leaf lists, GPU build vs oracle build"
+    assert_bits_equal(gh, gg, "box geometry, GPU build vs host build")
+    assert np.array_equal(th, tg) and np.array_equal(rh, rg), "GPU build vs host build"
     print(f"[{which}] host build ({threads} threads) {t1 - t0:.2f} s, GPU build {t2 - t1:.2f} s (includes OBJ load + make_triangle), "
-          f"{len(gh)} boxes, {len(rh)} references")
-    # a frame from the GPU-built tree is the frame from the host-built tree
-    vp = R.canonical_viewport(48, 48, 5, 2)
-    a = np.zeros((48, 48, 4), np.float32)
-    b = np.zeros_like(a)
-    R.HipRayCaster(seed=3).walk_rays(vp, host, a, 1, False)
-    R.HipRayCaster(seed=3).walk_rays(vp, gpu, b, 1, False)
-    assert_bits_equal(a, b, "frames")
+          f"{len(gg)} boxes, {len(rg)} references")
+    # a frame from the GPU-built tree is the oracle's frame
+    vo, vp = _viewports(48, 48, 5, 2)
+    ref, cn = so.render(48, 48, vo, 5, 2, seed=3, threads=8)
+    b = np.zeros((48, 48, 4), np.float32)
+    ctx = R.HipRayCaster(seed=3).walk_rays(vp, gpu, b, 1, False)
+    assert_bits_equal(ref, b, "frame from the GPU-built tree vs the oracle")
+    assert ctx.total_rays == cn["rays"]
 
 
 def test_pool_kernel_is_bit_exact(canonical_pair):
