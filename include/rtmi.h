@@ -87,10 +87,13 @@ typedef struct rtmi_stats {
     double render_ms;       /* rtmi_render_tile_device of this scene's tile                                  */
     double band_copy_ms;    /* (quantise +) the band's one crossing to the root device, synchronised           */
     double deinterleave_ms; /* scenes[0] only: k_deinterleave (+ the copy to out_host)                         */
+    /* fused path pipeline (rtmi_tuning_t.pipeline): the two kernels of trace_ms apart, summed over streams and batches */
+    double primary_ms;      /* k_path_primary launches (pixel_ray + closest hit + color_ray of the primary rays)  */
+    double bounce_ms;       /* k_path_bounce launches (every bounce of every path, shaded in place)               */
     int32_t peer_access;    /* 1 = this device writes the root device's memory directly (peer access enabled, or the
                              * same device); 0 = the runtime refused: the band is staged (rtmi_last_error() carries a
                              * warning although the call returns RTMI_OK)                                      */
-    uint32_t reserved;
+    uint32_t pipeline;      /* which pipeline rendered: 1 = one launch per bounce pass, 2 = fused path kernels     */
 } rtmi_stats_t;
 
 /* A set of image rows: `nrows` rows taken in stripes of `stripe_rows`

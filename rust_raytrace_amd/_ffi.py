@@ -18,7 +18,8 @@ class Stats(C.Structure):
                 ("full_tests", C.c_uint64), ("nodes", C.c_uint64), ("leaves", C.c_uint64),
                 ("kernel_ms", C.c_double), ("trace_ms", C.c_double), ("trace_launches", C.c_uint32),
                 ("streams", C.c_uint32), ("render_ms", C.c_double), ("band_copy_ms", C.c_double),
-                ("deinterleave_ms", C.c_double), ("peer_access", C.c_int32), ("reserved", C.c_uint32)]
+                ("deinterleave_ms", C.c_double), ("primary_ms", C.c_double), ("bounce_ms", C.c_double),
+                ("peer_access", C.c_int32), ("pipeline", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

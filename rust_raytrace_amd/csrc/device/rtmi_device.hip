@@ -38,7 +38,7 @@
 #include "vec4.hpp"
 
 // layouts the language bindings mirror (rust_raytrace_amd/_ffi.py, INTEGRATION.md ffi.rs; tests/test_host_cpu.py)
-static_assert(sizeof(rtmi_stats_t) == 104 && sizeof(rtmi_tuning_t) == 48 && sizeof(rtmi_tile_t) == 16 && sizeof(rtmi_box_t) == 32 &&
+static_assert(sizeof(rtmi_stats_t) == 120 && sizeof(rtmi_tuning_t) == 48 && sizeof(rtmi_tile_t) == 16 && sizeof(rtmi_box_t) == 32 &&
               sizeof(rtmi_triangle_t) == 104 && sizeof(rtmi_viewport_t) == 64 && sizeof(rtmi_sphere_t) == 40, "ABI struct layout changed");
 
 namespace rtmi {
@@ -74,20 +74,6 @@ struct DScene {
     uint32_t olevels;
 };
 #define RTMI_FN_WIDE 0x10000u
-
-struct DView {
-    V4 orig, cam, vu, vv;
-    uint32_t width, height, maxdepth, spp;
-    uint32_t row0, stripe_rows, stripe_step, pad;  // rtmi_tile_t: which image rows the local rows are
-};
-
-// local pixel index of the tile (row-major over the tile's rows) -> image (row, col)
-__device__ inline void tile_pixel(const DView& v, uint32_t lp, uint32_t& row, uint32_t& col) {
-    const uint32_t lr = lp / v.width;
-    col = lp - lr * v.width;
-    const uint32_t k = lr / v.stripe_rows;
-    row = v.row0 + k * v.stripe_step + (lr - k * v.stripe_rows);
-}
 
 // which octree kernel tune.kernel == 0 selects (measured on MI355X)
 #define RTMI_DEFAULT_POOL 0
@@ -347,6 +333,7 @@ __global__ void __launch_bounds__(256) k_trace(DScene sc, const float4* __restri
 }  // namespace rtmi
 #include "make_triangle.hpp"
 #include "build_octree.hpp"
+#include "shade.hpp"
 #include "trace_oct.hpp"
 #include "trace_pool.hpp"
 #include "bvh_fast.hpp"
@@ -467,37 +454,15 @@ __global__ void __launch_bounds__(256) k_trace_linear(DScene sc, const float4* _
     }
 }
 
-// ---------------------------------------------------------------- generation / shading
-struct RayV { V4 orig, dir; };
-// make_ray (raytrace.rs:201-210); inv_dir is recomputed by the trace kernel
-__device__ inline RayV make_ray(V4 orig, V4 dir) { return RayV{orig, vunit(dir)}; }
-
-// Viewport::pixel_ray (raytrace.rs:1374-1394), px = (row, col)
-__device__ inline RayV pixel_ray(const DView& v, uint32_t row, uint32_t col, uint64_t seed, uint32_t pixel, uint32_t sample) {
-    float px_x = (float)row, px_y = (float)col;
-    V4 vu_delta = vmul(v.vu, 1.f / (float)v.width);
-    V4 vv_delta = vmul(v.vv, 1.f / (float)v.height);
-    float u_off = 0.5f, v_off = 0.5f;
-    if (v.spp != 1) {
-        uint32_t w[4];
-        rng_block(seed, pixel, sample, 0, w);
-        u_off = u32_to_unit_f32(w[0]);
-        v_off = u32_to_unit_f32(w[1]);
-    }
-    V4 vu_frac = vmul(vu_delta, px_y + u_off);
-    V4 vv_frac = vmul(vv_delta, px_x + v_off);
-    V4 px_u = vadd(vadd(v.orig, vu_frac), vv_frac);
-    return make_ray(px_u, vunit(vsub(px_u, v.cam)));
-}
-
+// ---------------------------------------------------------------- generation / shading (per-pass pipeline)
+// pixel_ray / color_ray themselves are in shade.hpp (shared with the fused path kernels of trace_oct.hpp).
 __global__ void __launch_bounds__(256) k_gen(DView v, uint64_t seed, uint32_t pix0, uint32_t npaths,
                                              float4* __restrict__ qo, float4* __restrict__ qd,
                                              uint32_t* __restrict__ qpath, DCtrl* __restrict__ ctrl) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t path = blockIdx.x * blockDim.x + threadIdx.x; path < npaths; path += stride) {
-        const uint32_t lp = pix0 + path / v.spp, sample = path % v.spp;
-        uint32_t row, col;
-        tile_pixel(v, lp, row, col);
+        uint32_t row, col, sample;
+        path_pixel(v, pix0, path, row, col, sample);
         const uint32_t pixel = row * v.width + col;
         RayV r = pixel_ray(v, row, col, seed, pixel, sample);
         qo[path] = make_float4(r.orig.x, r.orig.y, r.orig.z, r.orig.w);
@@ -506,15 +471,6 @@ __global__ void __launch_bounds__(256) k_gen(DView v, uint64_t seed, uint32_t pi
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->count[0] = npaths;
 }
-
-// random_vec (raytrace.rs:188-192): k-th call of the path uses RNG block k
-__device__ inline V4 random_vec(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t k) {
-    uint32_t w[4];
-    rng_block(seed, pixel, sample, k, w);
-    return vunit(mk(u32_to_unit_f32(w[0]) - 0.5f, u32_to_unit_f32(w[1]) - 0.5f, u32_to_unit_f32(w[2]) - 0.5f));
-}
-// mix_color (raytrace.rs:299-301)
-__device__ inline V4 mix_color(V4 c1, V4 c2, float a) { return vadd(vmul(c1, 1.f - a), vmul(c2, a)); }
 
 // color_ray + the tail of project_ray for every ray of pass `pass`.
 __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed, uint32_t pix0, uint32_t npaths, int pass,
@@ -527,7 +483,6 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed
     const uint32_t count = ctrl->count[pass];
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t depth = v.maxdepth - (uint32_t)pass;  // remaining depth of the rays of this pass (>= 1)
     // round the loop bound up so that whole waves stay converged for the ballot
     const uint32_t bound = (count + 63u) & ~63u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < bound; i += stride) {
@@ -535,69 +490,15 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed
         RayV nr;
         uint32_t path = 0;
         if (i < count) {
+            // everything the ray needs is requested up front: the loads do not depend on each other
             path = qpath[i];
             const uint32_t tf = hit_tf[i];
-            const uint32_t tri = tf & 0x3FFFFFFFu, face = tf >> 30;
-            const uint32_t sample = path % v.spp;
-            uint32_t prow, pcol;
-            tile_pixel(v, pix0 + path / v.spp, prow, pcol);
-            const uint32_t pixel = prow * v.width + pcol;
-            V4 c;
-            uint32_t npushed = (uint32_t)pass;
-            if (tri == 0) {
-                c = mk(128.f / 255.f, 180.f / 255.f, 255.f / 255.f);  // raytrace.rs:1264
-            } else if (face & 2u) {
-                c = mk(0.f / 255.f, 0.f / 255.f, 0.f / 255.f);  // edge faces are Solid black, raytrace.rs:452-457
-            } else {
-                // a triangle's record, or (hit index >= ntris) an analytic sphere's: the sphere's normal needs the hit
-                // point and is filled in below
-                const bool is_sphere = tri >= sc.ntris;
-                const float4 p1 = is_sphere ? sc.spheres[2 * (tri - sc.ntris) + 1] : sc.tplane[2 * tri + 1];
-                const uint32_t mat = __float_as_uint(is_sphere ? p1.x : p1.w);
-                const float4 m0 = sc.mats[2 * mat], m1 = sc.mats[2 * mat + 1];
-                const uint32_t kind = __float_as_uint(m1.y);
-                if (kind == RTMI_SOLID) {
-                    c = mk(m0.x, m0.y, m0.z);
-                } else {
-                    mstack[(size_t)pass * npaths + path] = (uint16_t)mat;
-                    npushed = (uint32_t)pass + 1;
-                    c = mk(0.f / 255.f, 0.f / 255.f, 0.f / 255.f);  // project_ray at depth 0, raytrace.rs:1261-1263
-                    if (depth - 1 != 0) {
-                        const float4 o4 = qo[i], d4 = qd[i];
-                        const V4 ro{o4.x, o4.y, o4.z, o4.w}, rd{d4.x, d4.y, d4.z, d4.w};
-                        const float t = hit_t[i];
-                        const V4 point = vadd(vmul(rd, t), ro);                      // Ray::at, raytrace.rs:227-229
-                        V4 norm = mk(p1.x, p1.y, p1.z);
-                        if (is_sphere) {  // (point - center).unit()
-                            const float4 sc0 = sc.spheres[2 * (tri - sc.ntris)];
-                            norm = vunit(vsub(point, mk(sc0.x, sc0.y, sc0.z)));
-                        }
-                        if (face & 1u) norm = vmul(norm, -1.f);                       // raytrace.rs:441-449
-                        const V4 rv = random_vec(seed, pixel, sample, (uint32_t)pass + 1);
-                        if (kind == RTMI_MATTE) {
-                            nr = make_ray(vadd(point, vmul(rv, 0.001f)), vadd(norm, rv));  // lambertian_ray, :292-297
-                        } else {
-                            const float ddot = fabsf(vdot(rd, norm));                 // reflect_ray, :278-290
-                            const V4 dir_p = vmul(norm, ddot);
-                            const V4 dir_o = vadd(rd, dir_p);
-                            const V4 reflect = vadd(dir_p, dir_o);
-                            const V4 rvf = vmul(rv, m1.x);
-                            const V4 reflect_dir = vunit(vadd(reflect, rvf));
-                            nr = make_ray(vadd(point, vmul(reflect_dir, 0.001f)), vunit(vadd(reflect, rvf)));
-                        }
-                        push = true;
-                    }
-                }
-            }
-            if (!push) {
-                // inside-out evaluation of the nested mix_color calls (raytrace.rs:1233-1251)
-                for (int j = (int)npushed - 1; j >= 0; j--) {
-                    const uint32_t mj = mstack[(size_t)j * npaths + path];
-                    const float4 mm = sc.mats[2 * mj];
-                    c = mix_color(mk(mm.x, mm.y, mm.z), c, mm.w);
-                }
-                scol[path] = make_float4(c.x, c.y, c.z, c.w);
-            }
+            const float t = hit_t[i];
+            const float4 o4 = qo[i], d4 = qd[i];
+            uint32_t prow, pcol, sample;
+            path_pixel(v, pix0, path, prow, pcol, sample);
+            push = shade_hit(sc, v.maxdepth, seed, npaths, path, prow * v.width + pcol, sample, (uint32_t)pass, tf, t,
+                             V4{o4.x, o4.y, o4.z, o4.w}, V4{d4.x, d4.y, d4.z, d4.w}, mstack, scol, nr);
         }
         // compact surviving rays into the next queue: ballot + prefix sum, one atomic per wave
         const unsigned long long mask = __ballot(push);
@@ -706,6 +607,10 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 // HIP status -> ABI status: out of memory, "no device visible" and every other runtime failure are told apart
 static int hip_code(hipError_t e) {
+    // the failure is reported through the ABI's own channel (status + rtmi_last_error); what the runtime keeps pending for
+    // the thread's next hipGetLastError() is dropped, so that the CALLER's next HIP call (PyTorch polls after every
+    // operation) does not inherit this library's error
+    (void)hipGetLastError();
     if (e == hipErrorOutOfMemory) return RTMI_ERR_OOM;
     if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return RTMI_ERR_NO_DEVICE;
     return RTMI_ERR_DEVICE;
@@ -747,6 +652,7 @@ using namespace rtmi;
 struct Work {
     size_t cap = 0;
     uint32_t cap_depth = 0;
+    bool full = false;  // both queues + hit records allocated (per-pass pipeline, rtmi_trace)
     DevBuf<float4> qo[2], qd[2], scol;
     DevBuf<uint32_t> qpath[2], hit_tf;
     DevBuf<float> hit_t;
@@ -760,7 +666,7 @@ struct Work {
         for (int k = 0; k < 2; k++) if (ev[k]) { (void)hipEventDestroy(ev[k]); ev[k] = nullptr; }
         for (hipEvent_t e : pass_ev) (void)hipEventDestroy(e);
         pass_ev.clear();
-        cap = 0; cap_depth = 0;
+        cap = 0; cap_depth = 0; full = false;
     }
 };
 
@@ -1170,20 +1076,26 @@ int rtmi_scene_set_tuning(rtmi_scene_t* s, const rtmi_tuning_t* in) {
     return RTMI_OK;
 }
 
-static int ensure_workspace(Work& w, size_t cap, uint32_t maxdepth) {
-    if (cap <= w.cap && maxdepth <= w.cap_depth) return RTMI_OK;
+// fused = the path kernels only: ONE ray queue (the bounce rays of the primary pass), no hit records -- 62 B per path at
+// depth 5 instead of 106
+static int ensure_workspace(Work& w, size_t cap, uint32_t maxdepth, bool fused) {
+    if (cap <= w.cap && maxdepth <= w.cap_depth && (fused || w.full)) return RTMI_OK;
     cap = std::max(cap, w.cap);
     maxdepth = std::max(maxdepth, w.cap_depth);
-    for (int k = 0; k < 2; k++) {
+    const bool full = w.full || !fused;
+    for (int k = 0; k < (full ? 2 : 1); k++) {
         HIPCHK(w.qo[k].ensure(cap));
         HIPCHK(w.qd[k].ensure(cap));
         HIPCHK(w.qpath[k].ensure(cap));
     }
     HIPCHK(w.scol.ensure(cap));
-    HIPCHK(w.hit_tf.ensure(cap));
-    HIPCHK(w.hit_t.ensure(cap));
+    if (full) {
+        HIPCHK(w.hit_tf.ensure(cap));
+        HIPCHK(w.hit_t.ensure(cap));
+    }
+    w.full = full;
     HIPCHK(w.mstack.ensure(cap * (size_t)maxdepth));
-    while (w.pass_ev.size() < 2 * (size_t)std::max<uint32_t>(maxdepth, 1u)) {
+    while (w.pass_ev.size() < 2 * (size_t)std::max<uint32_t>(maxdepth, 2u)) {
         hipEvent_t e;
         HIPCHK(hipEventCreate(&e));
         w.pass_ev.push_back(e);
@@ -1225,12 +1137,14 @@ static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* q
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_pool<COUNT, false>), pgrid, block, s->pool_lds, st, s->d, qo, qd, w.ctrl.p, pass,
                                    w.hit_tf.p, w.hit_t.p, refill, xcd, s->pool_P, s->pool_stride);
-        } else if (s->options & RTMI_OPT_FAST)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT, true>), grid, block, s->oct_lds, st, s->d, qo, qd, w.ctrl.p, pass,
-                               w.hit_tf.p, w.hit_t.p, refill, xcd);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT, false>), grid, block, s->oct_lds, st, s->d, qo, qd, w.ctrl.p, pass,
-                               w.hit_tf.p, w.hit_t.p, refill, xcd);
+        } else {
+            OctArgs a{};
+            a.qo = qo; a.qd = qd; a.hit_tf = w.hit_tf.p; a.hit_t = w.hit_t.p; a.pass = pass;
+            if (s->options & RTMI_OPT_FAST)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT, true>), grid, block, s->oct_lds, st, s->d, a, w.ctrl.p, refill, xcd);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT, false>), grid, block, s->oct_lds, st, s->d, a, w.ctrl.p, refill, xcd);
+        }
     } else {
         // persistent grid: enough blocks to fill every CU at the occupancy LDS allows
         const int per_cu = s->trace_block == 256 ? 4 : 16;
@@ -1241,6 +1155,29 @@ static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* q
     (void)hipEventRecord(stop, st);
     if (s->d.nspheres)  // analytic spheres: a flat list against every ray, after the tree (not part of the timed trace kernel)
         hipLaunchKernelGGL(k_trace_spheres, dim3((unsigned)(s->num_cu * 8)), dim3(256), 0, st, s->d, qo, qd, w.ctrl.p, pass, w.hit_tf.p, w.hit_t.p);
+}
+// The fused path kernels (trace_oct.hpp): which = W_PRIMARY or W_BOUNCE.  `stop` is recorded right after the kernel.
+template <bool COUNT>
+static void launch_path(rtmi_scene* s, Work& w, hipStream_t st, int which, const DView& dv, uint64_t seed, uint32_t pix0, uint32_t npaths,
+                        hipEvent_t stop) {
+    const int per_cu = s->tune.oct_waves_per_cu ? (int)s->tune.oct_waves_per_cu
+                                                 : s->active_streams > 1 ? std::min(s->oct_blocks_per_cu, 16) : s->oct_blocks_per_cu;
+    const dim3 grid((unsigned)(s->num_cu * per_cu)), block(64);
+    const int refill = (int)(which == W_PRIMARY ? s->tune.refill_min0 : s->tune.refill_min);
+    const int xcd = (int)(s->tune.xcd_aware % 3u);
+    OctArgs a{};
+    a.v = dv; a.seed = seed; a.pix0 = pix0; a.npaths = npaths;
+    a.bqo = w.qo[0].p; a.bqd = w.qd[0].p; a.bqpath = w.qpath[0].p;
+    a.mstack = w.mstack.p; a.scol = w.scol.p;
+    const bool fast = (s->options & RTMI_OPT_FAST) != 0;
+    if (which == W_PRIMARY) {
+        if (fast) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_path_primary<COUNT, true>), grid, block, s->oct_lds, st, s->d, a, w.ctrl.p, refill, xcd);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_path_primary<COUNT, false>), grid, block, s->oct_lds, st, s->d, a, w.ctrl.p, refill, xcd);
+    } else {
+        if (fast) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_path_bounce<COUNT, true>), grid, block, s->oct_lds, st, s->d, a, w.ctrl.p, refill, xcd);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_path_bounce<COUNT, false>), grid, block, s->oct_lds, st, s->d, a, w.ctrl.p, refill, xcd);
+    }
+    (void)hipEventRecord(stop, st);
 }
 }  // extern "C++"
 
@@ -1323,6 +1260,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
         dv.vv = mk(vp->vv[0], vp->vv[1], vp->vv[2]);
         dv.width = W; dv.height = vp->height; dv.maxdepth = maxdepth; dv.spp = spp;
         dv.row0 = row0 + t * step; dv.stripe_rows = S; dv.stripe_step = step * nsub; dv.pad = 0;
+        view_set_divisors(dv);
         uint64_t rows = 0;
         for (uint32_t k = t; k < nstripes; k += nsub) rows += std::min<uint32_t>(S, nrows - k * S);
         sub[t].npix = rows * W;
@@ -1342,15 +1280,20 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     }
     pix_per_batch = std::min<uint64_t>(pix_per_batch, max_sub_npix);
     if (pix_per_batch * spp >= (1ull << 31)) return fail(RTMI_ERR_UNSUPPORTED, "batch above 2^31 paths");
+    // fused path kernels (pipeline 2, the default): exact-octree scenes traced by k_trace_oct's walk; everything else
+    // (linear list, generic tree, BVH mode, ray-pool kernel, analytic spheres) runs one launch per bounce pass
+    const bool pool_kernel = s->pool_P != 0 && s->tune.kernel != 1u && (s->tune.kernel == 2u || RTMI_DEFAULT_POOL);
+    const bool fused = s->tune.pipeline != 1u && s->octree && !s->root_is_leaf && !(s->options & (RTMI_OPT_GENERIC | RTMI_OPT_BVH)) &&
+                       !pool_kernel && s->d.nspheres == 0;
     for (uint32_t t = 0; t < nsub; t++) {
-        int rc = ensure_workspace(s->w[t], (size_t)(std::min<uint64_t>(pix_per_batch, sub[t].npix) * spp), maxdepth);
+        int rc = ensure_workspace(s->w[t], (size_t)(std::min<uint64_t>(pix_per_batch, sub[t].npix) * spp), maxdepth, fused);
         if (rc != RTMI_OK) return rc;
     }
 
     const bool counting = (s->options & RTMI_OPT_COUNTERS) != 0;
     const bool verbose = s->verbose;
     const unsigned ew_blocks = (unsigned)(s->num_cu * 8);
-    float trace_ms = 0.f;
+    float trace_ms = 0.f, primary_ms = 0.f, bounce_ms = 0.f;
     uint32_t launches = 0;
     // internal streams start after whatever the caller queued on its stream
     HIPCHK(hipEventRecord(s->fork_ev, ust));
@@ -1369,6 +1312,21 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
             const uint32_t pix0 = (uint32_t)p0;  // local pixel index inside the sub-tile
             HIPCHK(hipMemsetAsync(w.ctrl.p, 0, sizeof(DCtrl), st));
             HIPCHK(hipEventRecord(w.ev[0], st));
+            if (fused) {
+                // primary rays generated, traced and shaded in one kernel; every bounce of every path in one more
+                HIPCHK(hipEventRecord(w.pass_ev[0], st));
+                if (counting) launch_path<true>(s, w, st, W_PRIMARY, dv, seed, pix0, npaths, w.pass_ev[1]);
+                else launch_path<false>(s, w, st, W_PRIMARY, dv, seed, pix0, npaths, w.pass_ev[1]);
+                HIPCHK(hipGetLastError());  // a refused launch is reported where it happens, not at the end of the batch
+                launches++;
+                if (maxdepth > 1) {
+                    HIPCHK(hipEventRecord(w.pass_ev[2], st));
+                    if (counting) launch_path<true>(s, w, st, W_BOUNCE, dv, seed, pix0, npaths, w.pass_ev[3]);
+                    else launch_path<false>(s, w, st, W_BOUNCE, dv, seed, pix0, npaths, w.pass_ev[3]);
+                    HIPCHK(hipGetLastError());
+                    launches++;
+                }
+            } else {
             hipLaunchKernelGGL(k_gen, dim3(ew_blocks), dim3(256), 0, st, dv, seed, pix0, npaths, w.qo[0].p, w.qd[0].p, w.qpath[0].p, w.ctrl.p);
             HIPCHK(hipGetLastError());  // a refused launch is reported where it happens, not at the end of the batch
             for (uint32_t pass = 0; pass < maxdepth; pass++) {
@@ -1399,6 +1357,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
                 HIPCHK(hipGetLastError());
                 launches++;
             }
+            }
             hipLaunchKernelGGL(k_accum, dim3(ew_blocks), dim3(256), 0, st, np, spp, w.scol.p, out, pix0, W, S, nsub, t);
             HIPCHK(hipEventRecord(w.ev[1], st));
             HIPCHK(hipGetLastError());
@@ -1412,10 +1371,12 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
             if (rc != RTMI_OK) return rc;
             DCtrl hc;
             if (verbose) HIPCHK(hipMemcpy(&hc, w.ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost));
-            for (uint32_t pass = 0; pass < maxdepth; pass++) {
+            const uint32_t ntimed = fused ? (maxdepth > 1 ? 2u : 1u) : maxdepth;  // fused: primary kernel, bounce kernel
+            for (uint32_t pass = 0; pass < ntimed; pass++) {
                 float pm = 0.f;
                 HIPCHK(hipEventElapsedTime(&pm, w.pass_ev[2 * pass], w.pass_ev[2 * pass + 1]));
                 trace_ms += pm;
+                if (fused) { if (pass == 0) primary_ms += pm; else bounce_ms += pm; }
                 if (verbose) fprintf(stderr, "[rtmi] stream %u batch@%llu pass %u: %u rays, trace %.3f ms, %.1f Mrays/s\n", t, (unsigned long long)p0, pass, hc.count[pass], pm, hc.count[pass] / (pm * 1e3));
             }
             if (stats) {
@@ -1433,7 +1394,10 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     HIPCHK(hipEventSynchronize(s->end_ev));
     float kernel_ms = 0.f;
     HIPCHK(hipEventElapsedTime(&kernel_ms, s->fork_ev, s->end_ev));
-    if (stats) { stats->kernel_ms = kernel_ms; stats->trace_ms = trace_ms; stats->trace_launches = launches; stats->streams = nsub; }
+    if (stats) {
+        stats->kernel_ms = kernel_ms; stats->trace_ms = trace_ms; stats->trace_launches = launches; stats->streams = nsub;
+        stats->primary_ms = primary_ms; stats->bounce_ms = bounce_ms; stats->pipeline = fused ? 2u : 1u;
+    }
     return RTMI_OK;
     RTMI_GUARD_END
 }
@@ -1593,7 +1557,7 @@ int rtmi_trace(rtmi_scene_t* s, uint64_t n, const float* orig4, const float* dir
     RTMI_GUARD_BEGIN
     HIPCHK(hipSetDevice(s->device));
     Work& w = s->w[0];
-    int rc = ensure_workspace(w, (size_t)n, 1);
+    int rc = ensure_workspace(w, (size_t)n, 1, false);
     if (rc != RTMI_OK) return rc;
     hipStream_t st = s->istream[0];
     HIPCHK(hipMemcpyAsync(w.qo[0].p, orig4, n * 16, hipMemcpyHostToDevice, st));
@@ -1617,6 +1581,12 @@ int rtmi_trace(rtmi_scene_t* s, uint64_t n, const float* orig4, const float* dir
     if (stats) stats->streams = 1;
     return rc;
     RTMI_GUARD_END
+}
+
+// Test hook (not in rtmi.h): the ABI status and message a HIP runtime failure `hip_error` is reported as.
+int rtmi_debug_status_of(int hip_error) {
+    HIPCHK((hipError_t)hip_error);
+    return RTMI_OK;
 }
 
 // Development aid (not in rtmi.h): step statistics of the last counting render/trace.

@@ -56,7 +56,35 @@
 
 namespace rtmi {
 
-enum : uint32_t { M_IDLE = 0, M_SELECT = 1, M_LEAF = 2 };
+enum : uint32_t { M_IDLE = 0, M_SELECT = 1, M_LEAF = 2, M_SHADE = 3 };
+
+// What a lane does when its ray's root frame is finished -- the three kernels share one walk (oct_walk):
+//   W_TRACE    k_trace_oct     rays come from a queue, the closest hit goes to hit_tf / hit_t (one launch per bounce pass
+//                              of the per-pass pipeline; rtmi_trace)
+//   W_PRIMARY  k_path_primary  pixel_ray() is evaluated by the lane that takes the path (no ray queue for primary rays),
+//                              the finished ray is shaded IN the kernel (color_ray, shade.hpp): terminal paths write their
+//                              sample colour, bounce rays are compacted into the bounce queue (ballot + prefix sum, one
+//                              atomic per wave).  Whole-wave refills keep the samples of a pixel in lockstep.
+//   W_BOUNCE   k_path_bounce   ONE persistent launch for every bounce of every path: a lane pulls a bounce ray, traces
+//                              it, shades it in place and -- when the path goes on -- re-seeds ITSELF with the next bounce
+//                              ray; when the path ends it folds the surface stack into the sample colour and pulls the
+//                              next queued ray.  The recursion project_ray -> color_ray -> project_ray
+//                              (raytrace.rs:1233-1251, :1256-1295) without pass boundaries: no per-pass queues, no
+//                              per-pass tails of the persistent waves, no hit records in memory.
+// Shading is a third step kind ("exchange"): finished lanes wait in M_SHADE until `refill_min` lanes are finished or idle
+// (or nothing else is left to do), then they are shaded together and, in the same step, every lane without a ray takes
+// one from the queue.  The arithmetic per path is the per-pass pipeline's (same device functions), so the image is
+// bit-identical; only which lane evaluates it, and when, differs.
+enum : int { W_TRACE = 0, W_PRIMARY = 1, W_BOUNCE = 2 };
+
+struct OctArgs {
+    // W_TRACE
+    const float4* qo; const float4* qd; uint32_t* hit_tf; float* hit_t; int pass;
+    // W_PRIMARY / W_BOUNCE
+    DView v; uint64_t seed; uint32_t pix0, npaths;
+    float4* bqo; float4* bqd; uint32_t* bqpath;  // bounce queue: filled by W_PRIMARY (ctrl->count[1] entries), drained by W_BOUNCE
+    uint16_t* mstack; float4* scol;
+};
 
 // Frame of an inner box: node = index of its record; w = visited octants (bits 0-7) | O_DONE | O_HAS;
 // t = best hit time inside this box's subtree so far (what the sibling-local skip rule compares against,
@@ -90,15 +118,21 @@ __device__ inline T ld_off32(const T* base, uint32_t byte_off) {
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)byte_off);
 }
 
-template <bool COUNT, bool FAST>
-__global__ void __launch_bounds__(64, 4) k_trace_oct(DScene sc, const float4* __restrict__ qo, const float4* __restrict__ qd,
-                                                  DCtrl* __restrict__ ctrl, int pass, uint32_t* __restrict__ hit_tf,
-                                                  float* __restrict__ hit_t, int refill_min, int xcd_aware) {
-    extern __shared__ uint32_t lds[];
+template <bool COUNT, bool FAST, int MODE>
+__device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCtrl* __restrict__ ctrl, uint32_t* __restrict__ lds,
+                                         int refill_min, int xcd_aware) {
     const int lane = threadIdx.x;  // one wave per block
     constexpr int NT = 64;
-    const uint32_t count = ctrl->count[pass];
+    // which queue of the control block this launch drains: W_TRACE pass `pass`, W_PRIMARY the implicit queue of all paths
+    // of the batch (slot 0), W_BOUNCE the bounce queue (slot 1)
+    const int pass = MODE == W_TRACE ? a.pass : (MODE == W_PRIMARY ? 0 : 1);
+    const uint32_t count = MODE == W_PRIMARY ? a.npaths : ctrl->count[pass];
     if (blockIdx.x == 0 && lane == 0) atomicAdd(&ctrl->rays, (unsigned long long)count);
+    const float4* __restrict__ qo = MODE == W_BOUNCE ? a.bqo : a.qo;
+    const float4* __restrict__ qd = MODE == W_BOUNCE ? a.bqd : a.qd;
+    uint32_t path = 0;    // W_PRIMARY / W_BOUNCE: the path this lane works for (slot of its sample colour)
+    uint32_t bounce = 0;  // bounces the path has behind it = the reference's maxdepth - depth of the ray being traced
+    uint32_t ncont = 0;   // W_BOUNCE: rays this lane cast beyond the queued ones (the "Rays" statistic)
     unsigned long long cnt[5] = {0, 0, 0, 0, 0};
     // COUNT only: S steps, S lanes, L steps, L lanes, refills, refill lanes, edge steps, edge lanes, then shader-clock
     // cycles (s_memtime) this wave spent in SELECT steps, LEAF steps, refills, and in total
@@ -129,37 +163,103 @@ __global__ void __launch_bounds__(64, 4) k_trace_oct(DScene sc, const float4* __
 
     for (;;) {
         const unsigned long long m_idle = __ballot(mode == M_IDLE);
-        if (m_idle == ~0ull && exhausted) break;
-        if (!exhausted && (__popcll(m_idle) >= refill_min || m_idle == ~0ull)) {
-            // ---- refill: idle lanes take consecutive queued rays
-            const uint32_t n = (uint32_t)__popcll(m_idle);
+        // lanes whose ray is finished and waits to be shaded (path kernels only)
+        const unsigned long long m_shade = MODE == W_TRACE ? 0ull : __ballot(mode == M_SHADE);
+        const unsigned long long m_x = m_shade | (exhausted ? 0ull : m_idle);  // lanes the exchange step would serve
+        if (MODE == W_TRACE ? (m_idle == ~0ull && exhausted) : ((m_idle | m_shade) == ~0ull && m_x == 0ull)) break;
+        if (m_x != 0ull && (__popcll(m_x) >= refill_min || (m_idle | m_shade) == ~0ull)) {
+            // ---- exchange step: finished rays are shaded, lanes without a ray take consecutive queued rays
             const unsigned long long t_r0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
-            if (COUNT && lane == 0) { dbg[4]++; dbg[5] += n; }
-            // XCD-aware work fetch: the queue is cut into 8 contiguous ranges, one per XCD (each XCD has its own
-            // L2, so the waves of an XCD walk one image region and share its boxes/triangles there).  A wave pulls
-            // from the range of the XCD it runs on and moves to the next range when that one is exhausted, so the
-            // ranges only steer locality, never correctness or balance.
-            uint32_t base = 0, hi = 0;
-            for (;;) {
-                const uint32_t x = (home + tries) % nranges;
-                hi = (uint32_t)(((unsigned long long)count * (x + 1)) / nranges);
-                const uint32_t lo = (uint32_t)(((unsigned long long)count * x) / nranges);
-                if (lane == 0) base = lo + atomicAdd(&ctrl->xhead[pass][x], n);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base < hi) break;
-                if (++tries == nranges) { exhausted = true; break; }
-            }
-            if (!exhausted && mode == M_IDLE) {
-                const uint32_t i = base + (uint32_t)__popcll(m_idle & lt_mask);
-                if (i < hi) {
-                    ridx = i;
-                    r = make_rayk(qo[i], qd[i]);
-                    // the root box itself is never slab-tested (raytrace.rs:1272 calls
-                    // get_object_intersection_for_ray on it directly): start with its frame
-                    fnode = 0; fw = 0; ft = 0.f; lvl = 0;
-                    ghave = false; gt = 0.f; gtf = 0;
-                    mode = M_SELECT;
+            bool start = false;     // this lane begins a new ray below
+            float4 no = make_float4(0.f, 0.f, 0.f, 0.f), nd = make_float4(0.f, 0.f, 1.f, 0.f);
+            uint32_t npath = path, nbounce = bounce;
+            if (MODE != W_TRACE) {
+                bool push = false;  // W_PRIMARY: the path goes on -> its bounce ray is queued for k_path_bounce
+                RayV nr;
+                if (mode == M_SHADE) {
+                    uint32_t prow, pcol, sample;
+                    path_pixel(a.v, a.pix0, path, prow, pcol, sample);
+                    const bool cont = shade_hit(sc, a.v.maxdepth, a.seed, a.npaths, path, prow * a.v.width + pcol, sample, bounce,
+                                                ghave ? gtf : 0u, gt, V4{r.ox, r.oy, r.oz, r.ow}, V4{r.dx, r.dy, r.dz, r.dw},
+                                                a.mstack, a.scol, nr);
+                    mode = M_IDLE;
+                    if (cont) {
+                        if (MODE == W_BOUNCE) {
+                            no = make_float4(nr.orig.x, nr.orig.y, nr.orig.z, nr.orig.w);
+                            nd = make_float4(nr.dir.x, nr.dir.y, nr.dir.z, nr.dir.w);
+                            nbounce = bounce + 1u;
+                            ncont++;
+                            start = true;
+                            mode = M_SELECT;  // (not idle: it keeps its lane)
+                        } else push = true;
+                    }
                 }
+                if (MODE == W_PRIMARY) {
+                    const unsigned long long mask = __ballot(push);
+                    if (mask) {
+                        uint32_t qb = 0;
+                        if (lane == 0) qb = atomicAdd(&ctrl->count[1], (uint32_t)__popcll(mask));
+                        qb = __builtin_amdgcn_readfirstlane(qb);
+                        if (push) {
+                            const uint32_t slot = qb + (uint32_t)__popcll(mask & lt_mask);
+                            a.bqo[slot] = make_float4(nr.orig.x, nr.orig.y, nr.orig.z, nr.orig.w);
+                            a.bqd[slot] = make_float4(nr.dir.x, nr.dir.y, nr.dir.z, nr.dir.w);
+                            a.bqpath[slot] = path;
+                        }
+                    }
+                }
+            }
+            const unsigned long long m_want = MODE == W_TRACE ? m_idle : __ballot(mode == M_IDLE);
+            if (!exhausted && m_want != 0ull) {
+                const uint32_t n = (uint32_t)__popcll(m_want);
+                if (COUNT && lane == 0) { dbg[4]++; dbg[5] += n; }
+                // XCD-aware work fetch: the queue is cut into 8 contiguous ranges, one per XCD (each XCD has its own
+                // L2, so the waves of an XCD walk one image region and share its boxes/triangles there).  A wave pulls
+                // from the range of the XCD it runs on and moves to the next range when that one is exhausted, so the
+                // ranges only steer locality, never correctness or balance.
+                uint32_t base = 0, hi = 0;
+                for (;;) {
+                    const uint32_t x = (home + tries) % nranges;
+                    hi = (uint32_t)(((unsigned long long)count * (x + 1)) / nranges);
+                    const uint32_t lo = (uint32_t)(((unsigned long long)count * x) / nranges);
+                    if (lane == 0) base = lo + atomicAdd(&ctrl->xhead[pass][x], n);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base < hi) break;
+                    if (++tries == nranges) { exhausted = true; break; }
+                }
+                if (!exhausted && mode == M_IDLE) {
+                    const uint32_t i = base + (uint32_t)__popcll(m_want & lt_mask);
+                    if (i < hi) {
+                        if (MODE == W_PRIMARY) {
+                            uint32_t prow, pcol, sample;
+                            path_pixel(a.v, a.pix0, i, prow, pcol, sample);
+                            const RayV pr = pixel_ray(a.v, prow, pcol, a.seed, prow * a.v.width + pcol, sample);
+                            no = make_float4(pr.orig.x, pr.orig.y, pr.orig.z, pr.orig.w);
+                            nd = make_float4(pr.dir.x, pr.dir.y, pr.dir.z, pr.dir.w);
+                            npath = i; nbounce = 0u;
+                            start = true;
+                        } else if (MODE == W_BOUNCE) {
+                            no = qo[i]; nd = qd[i];
+                            npath = a.bqpath[i]; nbounce = 1u;
+                            start = true;
+                        } else {
+                            ridx = i;
+                            r = make_rayk(qo[i], qd[i]);
+                            // the root box itself is never slab-tested (raytrace.rs:1272 calls
+                            // get_object_intersection_for_ray on it directly): start with its frame
+                            fnode = 0; fw = 0; ft = 0.f; lvl = 0;
+                            ghave = false; gt = 0.f; gtf = 0;
+                            mode = M_SELECT;
+                        }
+                    }
+                }
+            }
+            if (MODE != W_TRACE && start) {  // one place where a path kernel's lane takes a ray: bounce in place, or refill
+                r = make_rayk(no, nd);
+                path = npath; bounce = nbounce;
+                fnode = 0; fw = 0; ft = 0.f; lvl = 0;
+                ghave = false; gt = 0.f; gtf = 0;
+                mode = M_SELECT;
             }
             if (COUNT && lane == 0) dbg[10] += __builtin_amdgcn_s_memtime() - t_r0;
             // no `continue`: the step below runs in the same iteration (one back edge, fewer copies of the loop-carried state)
@@ -192,9 +292,11 @@ __global__ void __launch_bounds__(64, 4) k_trace_oct(DScene sc, const float4* __
                     }
                 }
                 if (fw & O_DONE) {  // the root frame is finished: the ray is
-                    hit_tf[ridx] = ghave ? gtf : 0u;
-                    hit_t[ridx] = ghave ? gt : 0.f;
-                    mode = M_IDLE;
+                    if (MODE == W_TRACE) {
+                        a.hit_tf[ridx] = ghave ? gtf : 0u;
+                        a.hit_t[ridx] = ghave ? gt : 0.f;
+                        mode = M_IDLE;
+                    } else mode = M_SHADE;  // shaded in the next exchange step, together with the other finished lanes
                 } else {
                     const uint4 q0 = ld_off32(sc.fnodes, fnode << 5), q1 = ld_off32(sc.fnodes, (fnode << 5) + 16u);
                     const float cx = __uint_as_float(q0.x), cy = __uint_as_float(q0.y), cz = __uint_as_float(q0.z);
@@ -349,6 +451,12 @@ __global__ void __launch_bounds__(64, 4) k_trace_oct(DScene sc, const float4* __
             if (stepS) dbg[8] += dt; else dbg[9] += dt;
         }
     }
+    if (MODE == W_BOUNCE) {  // "Rays": the queued bounce rays were counted above, the ones cast in place here
+        unsigned long long wsum = 0;
+        for (unsigned long long m = __ballot(ncont != 0u); m; m &= m - 1ull)
+            wsum += (uint32_t)__builtin_amdgcn_readlane((int)ncont, __ffsll((long long)m) - 1);
+        if (lane == 0 && wsum) atomicAdd(&ctrl->rays, wsum);
+    }
     if (COUNT) {
         if (lane == 0) dbg[11] = __builtin_amdgcn_s_memtime() - t_begin;
 #pragma unroll
@@ -358,6 +466,28 @@ __global__ void __launch_bounds__(64, 4) k_trace_oct(DScene sc, const float4* __
         for (int k = 0; k < 12; k++)
             if (dbg[k]) atomicAdd(&ctrl->dbg[k], dbg[k]);
     }
+}
+
+template <bool COUNT, bool FAST>
+__global__ void __launch_bounds__(64, 4) k_trace_oct(DScene sc, OctArgs a, DCtrl* __restrict__ ctrl, int refill_min, int xcd_aware) {
+    extern __shared__ uint32_t lds[];
+    oct_walk<COUNT, FAST, W_TRACE>(sc, a, ctrl, lds, refill_min, xcd_aware);
+}
+// 6 waves per SIMD = at most 80 VGPRs, the occupancy k_trace_oct has (24 waves per CU is where this walk peaks, DESIGN.md
+// 4.1).  The exchange step (Philox + shading with the whole traversal state live) needs ~95; with the cap hipcc keeps the
+// SELECT / LEAF steps spill-free and parks launch constants in scratch that only the (rare) exchange step reloads.
+#ifndef RTMI_PATH_WAVES
+#define RTMI_PATH_WAVES 6
+#endif
+template <bool COUNT, bool FAST>
+__global__ void __launch_bounds__(64, RTMI_PATH_WAVES) k_path_primary(DScene sc, OctArgs a, DCtrl* __restrict__ ctrl, int refill_min, int xcd_aware) {
+    extern __shared__ uint32_t lds[];
+    oct_walk<COUNT, FAST, W_PRIMARY>(sc, a, ctrl, lds, refill_min, xcd_aware);
+}
+template <bool COUNT, bool FAST>
+__global__ void __launch_bounds__(64, RTMI_PATH_WAVES) k_path_bounce(DScene sc, OctArgs a, DCtrl* __restrict__ ctrl, int refill_min, int xcd_aware) {
+    extern __shared__ uint32_t lds[];
+    oct_walk<COUNT, FAST, W_BOUNCE>(sc, a, ctrl, lds, refill_min, xcd_aware);
 }
 
 }  // namespace rtmi

@@ -681,6 +681,7 @@ void HipRayCaster::walk_frame_multi(const Viewport& v, const Scene& s, void* dat
         sum.kernel_ms = std::max(sum.kernel_ms, d.kernel_ms);  // the devices run concurrently
         sum.streams = std::max(sum.streams, d.streams);
         sum.render_ms = std::max(sum.render_ms, d.render_ms);
+        sum.primary_ms += d.primary_ms; sum.bounce_ms += d.bounce_ms; sum.pipeline = std::max(sum.pipeline, d.pipeline);
         sum.band_copy_ms = std::max(sum.band_copy_ms, d.band_copy_ms);
         sum.deinterleave_ms += d.deinterleave_ms;
     }

@@ -318,14 +318,18 @@ def test_peer_access_is_asked_once_and_leaves_nothing_pending():
 
 
 def test_oom_and_device_error_codes():
-    """RTMI_ERR_OOM and RTMI_ERR_DEVICE, provoked: an allocation no MI355X can satisfy (2^36 pixels x 16 B = 1 TiB; the
-    request fails before anything is read or written), and a HIP stream handle that has already been destroyed (the HIP
-    runtime rejects it at the first enqueue).  Both leave the scene usable."""
+    """RTMI_ERR_OOM provoked for real: an allocation no MI355X can satisfy (2^36 pixels x 16 B = 1 TiB; the request fails
+    before anything is read or written).  The error must not stay pending in the HIP runtime either: PyTorch polls
+    hipGetLastError() after its own calls and would report this library's failure as its own (it did, before
+    hip_code() cleared it).  RTMI_ERR_DEVICE is what every other HIP runtime failure maps to; a real one (a faulting
+    kernel, a destroyed stream) cannot be provoked safely on a shared GPU host -- a stale hipStream_t segfaults inside
+    the runtime, a faulting kernel can reset the GPU for everyone -- so the mapping itself is checked through the
+    library's test hook for the statuses that matter."""
     from oracle import orc
     import torch
     L, ffi = _lib()
     L.rtmi_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
-    L.rtmi_render_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rtmi_debug_status_of.argtypes = [C.c_int]
     so = recipe_circles()(OracleApi(orc))
     tris, geo, topo, refs = _abi_arrays(so)
     rc, h = _create(L, tris, _boxes(geo, topo), refs)
@@ -334,20 +338,18 @@ def test_oom_and_device_error_codes():
         small = np.zeros(16, np.float32)
         assert L.rtmi_quantize(h, small.ctypes.data_as(C.c_void_p), 1 << 36, small.ctypes.data_as(C.c_void_p)) == RTMI_ERR_OOM
         assert b"memory" in L.rtmi_last_error().lower()
-        # a stream created and destroyed through the process's HIP runtime (the one torch loaded)
-        hip = C.CDLL("libamdhip64.so.7")  # already mapped (torch's): dlopen by SONAME returns the same runtime
-        hip.hipStreamCreate.argtypes = [C.c_void_p]
-        hip.hipStreamDestroy.argtypes = [C.c_void_p]
-        stale = C.c_void_p()
-        assert hip.hipStreamCreate(C.byref(stale)) == 0
-        assert hip.hipStreamDestroy(stale) == 0
+        dev = torch.zeros((8, 16, 4), dtype=torch.float32, device="cuda:0")  # raises if the OOM were still pending
+        torch.cuda.synchronize()
+        assert float(dev.sum()) == 0.0
+        # hipError_t -> ABI status (hip_runtime_api.h: 2 OutOfMemory, 100 NoDevice, 101 InvalidDevice, 700 IllegalAddress,
+        # 719 LaunchFailure, 1 InvalidValue, 400 InvalidHandle, 900 StreamCaptureUnsupported)
+        for hip_err, want in ((2, RTMI_ERR_OOM), (100, RTMI_ERR_NO_DEVICE), (101, RTMI_ERR_NO_DEVICE), (700, RTMI_ERR_DEVICE),
+                              (719, RTMI_ERR_DEVICE), (1, RTMI_ERR_DEVICE), (400, RTMI_ERR_DEVICE), (900, RTMI_ERR_DEVICE)):
+            assert L.rtmi_debug_status_of(hip_err) == want, hip_err
+            assert L.rtmi_last_error() != b""
+        # the handle still renders, and equals the oracle
         w, hgt = 16, 8
         vp12 = orc.canonical_viewport(w, hgt)
-        vp = Vp(w, hgt, (C.c_float * 3)(*vp12[0:3]), (C.c_float * 3)(*vp12[3:6]), (C.c_float * 3)(*vp12[6:9]), (C.c_float * 3)(*vp12[9:12]), 5, 2)
-        dev = torch.zeros((hgt, w, 4), dtype=torch.float32, device="cuda:0")
-        rc = L.rtmi_render_device(h, C.byref(vp), 1, 0, hgt, C.c_void_p(dev.data_ptr()), stale, None)
-        assert rc == RTMI_ERR_DEVICE, (rc, L.rtmi_last_error())
-        # the handle still renders, and equals the oracle
         ref, _ = so.render(w, hgt, vp12, 5, 2, seed=1, threads=4)
         img, _ = _render(L, ffi, h, vp12, w, hgt, 5, 2, 1)
         assert_bits_equal(ref, img, "render after the provoked errors")

@@ -772,6 +772,58 @@ def test_octree_build_on_gpu_equals_oracle_build(which, canonical_pair, grid_pai
     assert ctx.total_rays == cn["rays"]
 
 
+def test_fused_and_per_pass_pipelines_same_image(canonical_pair, circles_pair):
+    """The default pipeline renders an octree scene with the fused path kernels (k_path_primary: pixel_ray + closest hit +
+    color_ray of the primary rays; k_path_bounce: every bounce of every path in one persistent launch, shaded in place);
+    tuning pipeline=1 runs the same frame with one launch per bounce pass (k_gen, k_trace_oct + k_shade per pass).  Same
+    device functions, so: image bits, "Rays" and all work counters equal each other AND the oracle -- odd sizes, sample
+    counts that are not powers of two (the path -> (pixel, sample) mapping divides by them), depth limits 1..7, batches
+    smaller than a wave, refill thresholds 1..64, striped tiles."""
+    orc, R = _orc(), _R()
+    for pair, (w, h, spp, depth, seed) in ((canonical_pair, (97, 61, 3, 5, 5)), (canonical_pair, (64, 64, 1, 5, 1)),
+                                           (canonical_pair, (33, 47, 7, 1, 2)), (canonical_pair, (50, 20, 65, 3, 3)),
+                                           (circles_pair, (71, 53, 5, 7, 9)), (canonical_pair, (40, 36, 2, 2, 11))):
+        so, sp = pair
+        vo, vp = _viewports(w, h, depth, spp)
+        ref, cn = so.render(w, h, vo, depth, spp, seed=seed, threads=8)
+        imgs = {}
+        for pipe in (1, 2):
+            img = np.zeros((h, w, 4), np.float32)
+            ctx = R.HipRayCaster(seed=seed, options=R.OPT_COUNTERS, tuning={"pipeline": pipe}).walk_rays(vp, sp, img, 1, False)
+            assert ctx.stats["pipeline"] == pipe
+            assert_bits_equal(ref, img, f"pipeline {pipe} {w}x{h}@{spp} depth {depth}")
+            for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
+                assert ctx.stats[k] == cn[k], (pipe, k)
+            imgs[pipe] = img
+            assert ctx.stats["trace_launches"] == (depth if pipe == 1 else min(depth, 2)) * ctx.stats["streams"]
+        # uncounted kernels (the ones that are timed)
+        for pipe in (1, 2):
+            img = np.zeros((h, w, 4), np.float32)
+            ctx = R.HipRayCaster(seed=seed, tuning={"pipeline": pipe}).walk_rays(vp, sp, img, 1, False)
+            assert_bits_equal(ref, img, f"uncounted pipeline {pipe}")
+            assert ctx.total_rays == cn["rays"]
+    # tuning never changes a pixel: tiny batches (less than a wave of paths), every refill threshold, stream counts
+    so, sp = canonical_pair
+    w, h, spp = 45, 38, 3
+    vo, vp = _viewports(w, h, 5, spp)
+    ref, cn = so.render(w, h, vo, 5, spp, seed=21, threads=8)
+    for tun in ({"batch_paths": 40}, {"batch_paths": 1000, "streams": 2}, {"refill_min": 1, "refill_min0": 1}, {"refill_min": 64, "refill_min0": 64},
+                {"refill_min": 23, "refill_min0": 17, "streams": 4, "subtile_min_paths": 1}, {"oct_waves_per_cu": 1}, {"xcd_aware": 0},
+                {"xcd_aware": 2, "streams": 1}):
+        img = np.zeros((h, w, 4), np.float32)
+        ctx = R.HipRayCaster(seed=21, tuning=dict(tun, pipeline=2)).walk_rays(vp, sp, img, 1, False)
+        assert_bits_equal(ref, img, f"fused, tuning {tun}")
+        assert ctx.total_rays == cn["rays"], tun
+    # a striped tile (one rank of three) through the fused kernels equals those rows of the frame
+    import torch
+    from rust_raytrace_amd import dist as rd
+    tile = rd.rank_tile(1, 3, h, 4)
+    buf = torch.zeros((tile[1], w, 4), dtype=torch.float32, device="cuda:0")
+    R.HipRayCaster(seed=21, tuning={"pipeline": 2}).walk_tile_device(vp, sp, tile, buf.data_ptr())
+    torch.cuda.synchronize()
+    assert_bits_equal(ref[rd.tile_rows(tile, h)], buf.cpu().numpy(), "striped tile, fused")
+
+
 def test_pool_kernel_is_bit_exact(canonical_pair):
     """tuning kernel=2 selects k_trace_pool (per-wave ray pool in LDS, free ray-to-lane assignment each step); measured
     slower than the default on MI355X and therefore opt-in, but it stays exact: image bits and all six work
