@@ -93,7 +93,7 @@ typedef struct rtmi_stats {
     int32_t peer_access;    /* 1 = this device writes the root device's memory directly (peer access enabled, or the
                              * same device); 0 = the runtime refused: the band is staged (rtmi_last_error() carries a
                              * warning although the call returns RTMI_OK)                                      */
-    uint32_t pipeline;      /* which pipeline rendered: 1 = one launch per bounce pass, 2 = fused path kernels     */
+    uint32_t pipeline;      /* which pipeline rendered (rtmi_tuning_t.pipeline: 1, 2 or 3)                         */
 } rtmi_stats_t;
 
 /* A set of image rows: `nrows` rows taken in stripes of `stripe_rows`
@@ -176,14 +176,17 @@ typedef struct rtmi_tuning {
     uint32_t oct_waves_per_cu;  /* persistent waves per CU and launch of the octree kernel; 0 = automatic: what
                                    fits with one stream, at most 16 when several streams share the CUs       */
     uint32_t refill_min0;       /* idle lanes before a wave refills, primary pass (64 = whole wave); default 64 */
-    uint32_t refill_min;        /* the same for bounce passes; default 8                                       */
-    uint32_t xcd_aware;         /* 1 = one ray-queue range per XCD (by XCC_ID), 2 = by block index, 0 = one queue */
+    uint32_t refill_min;        /* the same for bounce passes (and the shading step of k_path_bounce); default 16       */
+    uint32_t xcd_aware;         /* 1 = one ray-queue range per XCD (by XCC_ID), 2 = by block index, 0 = one queue (default) */
     uint32_t kernel;            /* octree closest-hit kernel: 0 = automatic, 1 = one ray per lane (k_trace_oct),
                                  * 2 = per-wave ray pool in LDS (k_trace_pool; falls back to 1 for very deep trees) */
-    uint32_t pipeline;          /* 0 = automatic, 1 = one launch per bounce pass (k_gen, then k_trace* + k_shade per pass),
-                                 * 2 = fused path kernels: primary rays generated, traced and shaded in one kernel, all
-                                 * bounces in ONE persistent kernel that shades in place (octree scenes; anything else
-                                 * falls back to 1).  Environment: RTMI_PIPELINE.                                    */
+    uint32_t pipeline;          /* 0 = automatic (= 3), 1 = one launch per bounce pass (k_gen, then k_trace* + k_shade per
+                                 * pass), 2 = fused path kernels: primary rays generated, traced and shaded in one kernel
+                                 * (k_path_primary), all bounces in ONE persistent kernel that shades in place
+                                 * (k_path_bounce; 62 instead of 106 bytes of workspace per path), 3 = k_path_primary, then
+                                 * one closest-hit + one shading launch per bounce pass.  2 and 3 apply to octree scenes;
+                                 * anything else (linear list, generic tree, BVH mode, analytic spheres) runs 1.
+                                 * Same image whichever runs.  Environment: RTMI_PIPELINE.                              */
     uint32_t reserved;
 } rtmi_tuning_t;
 int rtmi_scene_get_tuning(rtmi_scene_t* scene, rtmi_tuning_t* out);

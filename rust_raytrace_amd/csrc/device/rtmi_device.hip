@@ -917,10 +917,10 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     s->tune.subtile_min_paths = (uint32_t)std::min<size_t>(env_size("RTMI_SUBTILE_MIN_PATHS", 32768), 0xFFFFFFFFu);
     s->tune.oct_waves_per_cu = (uint32_t)std::min<size_t>(env_size("RTMI_OCT_WAVES_PER_CU", 0), 32);
     s->tune.refill_min0 = (uint32_t)std::min<size_t>(env_size("RTMI_REFILL_MIN0", 64), 64);
-    s->tune.refill_min = (uint32_t)std::min<size_t>(env_size("RTMI_REFILL_MIN", 8), 64);
-    s->tune.xcd_aware = (uint32_t)(env_size("RTMI_XCD_AWARE", 1) % 3);
+    s->tune.refill_min = (uint32_t)std::min<size_t>(env_size("RTMI_REFILL_MIN", 16), 64);
+    s->tune.xcd_aware = (uint32_t)(env_size("RTMI_XCD_AWARE", 0) % 3);
     s->tune.kernel = (uint32_t)std::min<size_t>(env_size("RTMI_KERNEL", 0), 2);
-    s->tune.pipeline = (uint32_t)std::min<size_t>(env_size("RTMI_PIPELINE", 0), 2);
+    s->tune.pipeline = (uint32_t)std::min<size_t>(env_size("RTMI_PIPELINE", 0), 3);
     s->verbose = getenv("RTMI_VERBOSE") != nullptr;
     s->trace_block = block;
     s->trace_lds = (size_t)levels * 16 * block;
@@ -1070,7 +1070,7 @@ int rtmi_scene_get_tuning(rtmi_scene_t* s, rtmi_tuning_t* out) {
 int rtmi_scene_set_tuning(rtmi_scene_t* s, const rtmi_tuning_t* in) {
     if (!s || !in) return fail(RTMI_ERR_INVALID, "NULL argument");
     if (in->batch_paths == 0 || in->streams < 1 || in->streams > RTMI_MAX_STREAMS || in->oct_waves_per_cu > 32 || in->refill_min0 < 1 ||
-        in->refill_min0 > 64 || in->refill_min < 1 || in->refill_min > 64 || in->xcd_aware > 2 || in->kernel > 2 || in->pipeline > 2)
+        in->refill_min0 > 64 || in->refill_min < 1 || in->refill_min > 64 || in->xcd_aware > 2 || in->kernel > 2 || in->pipeline > 3)
         return fail(RTMI_ERR_INVALID, "tuning value out of range");
     s->tune = *in;
     return RTMI_OK;
@@ -1159,7 +1159,7 @@ static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* q
 // The fused path kernels (trace_oct.hpp): which = W_PRIMARY or W_BOUNCE.  `stop` is recorded right after the kernel.
 template <bool COUNT>
 static void launch_path(rtmi_scene* s, Work& w, hipStream_t st, int which, const DView& dv, uint64_t seed, uint32_t pix0, uint32_t npaths,
-                        hipEvent_t stop) {
+                        hipEvent_t stop, int queue = 0) {
     const int per_cu = s->tune.oct_waves_per_cu ? (int)s->tune.oct_waves_per_cu
                                                  : s->active_streams > 1 ? std::min(s->oct_blocks_per_cu, 16) : s->oct_blocks_per_cu;
     const dim3 grid((unsigned)(s->num_cu * per_cu)), block(64);
@@ -1167,7 +1167,7 @@ static void launch_path(rtmi_scene* s, Work& w, hipStream_t st, int which, const
     const int xcd = (int)(s->tune.xcd_aware % 3u);
     OctArgs a{};
     a.v = dv; a.seed = seed; a.pix0 = pix0; a.npaths = npaths;
-    a.bqo = w.qo[0].p; a.bqd = w.qd[0].p; a.bqpath = w.qpath[0].p;
+    a.bqo = w.qo[queue].p; a.bqd = w.qd[queue].p; a.bqpath = w.qpath[queue].p;
     a.mstack = w.mstack.p; a.scol = w.scol.p;
     const bool fast = (s->options & RTMI_OPT_FAST) != 0;
     if (which == W_PRIMARY) {
@@ -1283,10 +1283,13 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     // fused path kernels (pipeline 2, the default): exact-octree scenes traced by k_trace_oct's walk; everything else
     // (linear list, generic tree, BVH mode, ray-pool kernel, analytic spheres) runs one launch per bounce pass
     const bool pool_kernel = s->pool_P != 0 && s->tune.kernel != 1u && (s->tune.kernel == 2u || RTMI_DEFAULT_POOL);
+    // 0 = automatic = 3: fused primary kernel, then one launch per bounce pass on the sub-tiles' streams (measured fastest
+    // on MI355X at every tile size)
+    const bool hybrid_req = s->tune.pipeline == 3u || s->tune.pipeline == 0u;
     const bool fused = s->tune.pipeline != 1u && s->octree && !s->root_is_leaf && !(s->options & (RTMI_OPT_GENERIC | RTMI_OPT_BVH)) &&
                        !pool_kernel && s->d.nspheres == 0;
     for (uint32_t t = 0; t < nsub; t++) {
-        int rc = ensure_workspace(s->w[t], (size_t)(std::min<uint64_t>(pix_per_batch, sub[t].npix) * spp), maxdepth, fused);
+        int rc = ensure_workspace(s->w[t], (size_t)(std::min<uint64_t>(pix_per_batch, sub[t].npix) * spp), maxdepth, fused && !hybrid_req);
         if (rc != RTMI_OK) return rc;
     }
 
@@ -1312,7 +1315,27 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
             const uint32_t pix0 = (uint32_t)p0;  // local pixel index inside the sub-tile
             HIPCHK(hipMemsetAsync(w.ctrl.p, 0, sizeof(DCtrl), st));
             HIPCHK(hipEventRecord(w.ev[0], st));
-            if (fused) {
+            if (fused && hybrid_req) {
+                // primary rays generated, traced and shaded in one kernel (its bounce rays go to the queue pass 1 reads),
+                // then one closest-hit + one shading launch per bounce pass
+                HIPCHK(hipEventRecord(w.pass_ev[0], st));
+                if (counting) launch_path<true>(s, w, st, W_PRIMARY, dv, seed, pix0, npaths, w.pass_ev[1], 1);
+                else launch_path<false>(s, w, st, W_PRIMARY, dv, seed, pix0, npaths, w.pass_ev[1], 1);
+                HIPCHK(hipGetLastError());
+                launches++;
+                for (uint32_t pass = 1; pass < maxdepth; pass++) {
+                    const int a = pass & 1, b = a ^ 1;
+                    HIPCHK(hipEventRecord(w.pass_ev[2 * pass], st));
+                    if (counting) launch_trace<true>(s, w, st, w.qo[a].p, w.qd[a].p, (int)pass, w.pass_ev[2 * pass + 1]);
+                    else launch_trace<false>(s, w, st, w.qo[a].p, w.qd[a].p, (int)pass, w.pass_ev[2 * pass + 1]);
+                    HIPCHK(hipGetLastError());
+                    hipLaunchKernelGGL(k_shade, dim3(ew_blocks), dim3(256), 0, st, s->d, dv, seed, pix0, npaths, (int)pass,
+                                       w.qo[a].p, w.qd[a].p, w.qpath[a].p, w.hit_tf.p, w.hit_t.p, w.qo[b].p, w.qd[b].p,
+                                       w.qpath[b].p, w.mstack.p, w.scol.p, w.ctrl.p);
+                    HIPCHK(hipGetLastError());
+                    launches++;
+                }
+            } else if (fused) {
                 // primary rays generated, traced and shaded in one kernel; every bounce of every path in one more
                 HIPCHK(hipEventRecord(w.pass_ev[0], st));
                 if (counting) launch_path<true>(s, w, st, W_PRIMARY, dv, seed, pix0, npaths, w.pass_ev[1]);
@@ -1371,7 +1394,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
             if (rc != RTMI_OK) return rc;
             DCtrl hc;
             if (verbose) HIPCHK(hipMemcpy(&hc, w.ctrl.p, sizeof(DCtrl), hipMemcpyDeviceToHost));
-            const uint32_t ntimed = fused ? (maxdepth > 1 ? 2u : 1u) : maxdepth;  // fused: primary kernel, bounce kernel
+            const uint32_t ntimed = (fused && !hybrid_req) ? (maxdepth > 1 ? 2u : 1u) : maxdepth;  // fused: primary kernel, bounce kernel
             for (uint32_t pass = 0; pass < ntimed; pass++) {
                 float pm = 0.f;
                 HIPCHK(hipEventElapsedTime(&pm, w.pass_ev[2 * pass], w.pass_ev[2 * pass + 1]));
@@ -1396,7 +1419,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     HIPCHK(hipEventElapsedTime(&kernel_ms, s->fork_ev, s->end_ev));
     if (stats) {
         stats->kernel_ms = kernel_ms; stats->trace_ms = trace_ms; stats->trace_launches = launches; stats->streams = nsub;
-        stats->primary_ms = primary_ms; stats->bounce_ms = bounce_ms; stats->pipeline = fused ? 2u : 1u;
+        stats->primary_ms = primary_ms; stats->bounce_ms = bounce_ms; stats->pipeline = fused ? (hybrid_req ? 3u : 2u) : 1u;
     }
     return RTMI_OK;
     RTMI_GUARD_END

@@ -136,7 +136,10 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
     unsigned long long cnt[5] = {0, 0, 0, 0, 0};
     // COUNT only: S steps, S lanes, L steps, L lanes, refills, refill lanes, edge steps, edge lanes, then shader-clock
     // cycles (s_memtime) this wave spent in SELECT steps, LEAF steps, refills, and in total
-    unsigned long long dbg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // dbg[12..15]: plane tests whose `t < 0` follows from the signs and exponents of num / den alone (the quotient is a
+    // negative NORMAL number), (LEAF step, reference k) slots in which that holds for EVERY working lane -- the only case in
+    // which leaving out the division is a saving for the wave --, all such slots, LEAF steps in which all 4 slots are so
+    unsigned long long dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const float root_half = sc.root_half;
@@ -397,6 +400,7 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
                 // terms.  A reference that passes `t >= 0` and the bounding-radius test becomes the lane's pending
                 // candidate; its edge part runs below, once per step.
                 uint32_t ptri = 0u;
+                uint32_t allneg = 0u;  // COUNT only
                 float pt = 0.f, pix = 0.f, piy = 0.f, piz = 0.f, pden = 0.f;
                 auto resolve = [&]() {
                     // all four edge records are requested together and every comparison is evaluated (no
@@ -427,6 +431,12 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
                     const float l2 = ((ix * ix + iy * iy) + iz * iz) + pw * pw;
                     const bool real = ids[k] != 0u;
                     if (COUNT) cnt[1] += real ? 1u : 0u;
+                    if (COUNT) {
+                        const bool dec = !real | ((t <= -1.17549435e-38f) & (t >= -FLT_MAX));
+                        const unsigned long long wm = __ballot(true), dm = __ballot(dec);
+                        if (real & dec) dbg[12]++;
+                        if (lane == __ffsll((long long)wm) - 1) { dbg[14]++; if (dm == wm) { dbg[13]++; allneg++; } }
+                    }
                     const bool c = real & !(t < 0.f) & !(l2 > p0[k].w);
                     if (c & (ptri != 0u)) resolve();  // second candidate of this lane in one block: rare
                     ptri = c ? ids[k] : ptri;
@@ -435,6 +445,7 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
                     pden = c ? den : pden;
                 }
                 if (ptri != 0u) resolve();
+                if (COUNT && allneg == 4u) dbg[15]++;
                 if (!more) {
                     if (lhave) {
                         if (!(fw & O_HAS) || lt < ft) ft = lt;
@@ -463,13 +474,16 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
         for (int k = 0; k < 5; k++)
             if (cnt[k]) atomicAdd(&ctrl->counters[k], cnt[k]);
 #pragma unroll
-        for (int k = 0; k < 12; k++)
+        for (int k = 0; k < 16; k++)
             if (dbg[k]) atomicAdd(&ctrl->dbg[k], dbg[k]);
     }
 }
 
+#ifndef RTMI_TRACE_WAVES
+#define RTMI_TRACE_WAVES 4
+#endif
 template <bool COUNT, bool FAST>
-__global__ void __launch_bounds__(64, 4) k_trace_oct(DScene sc, OctArgs a, DCtrl* __restrict__ ctrl, int refill_min, int xcd_aware) {
+__global__ void __launch_bounds__(64, RTMI_TRACE_WAVES) k_trace_oct(DScene sc, OctArgs a, DCtrl* __restrict__ ctrl, int refill_min, int xcd_aware) {
     extern __shared__ uint32_t lds[];
     oct_walk<COUNT, FAST, W_TRACE>(sc, a, ctrl, lds, refill_min, xcd_aware);
 }

@@ -248,7 +248,7 @@ def test_small_batches_same_image(canonical_pair):
     R.HipRayCaster(seed=3, tuning={"batch_paths": 1000}).walk_rays(vp, sp, b, 1, False)  # forces many ragged batches
     assert_bits_equal(a, b, "batched")
     # launch tuning never changes a pixel: waves per CU, refill thresholds, ray-queue ranges
-    for tn in ({"oct_waves_per_cu": 3, "refill_min0": 1, "refill_min": 64}, {"xcd_aware": 0}, {"xcd_aware": 2, "refill_min0": 17}):
+    for tn in ({"oct_waves_per_cu": 3, "refill_min0": 1, "refill_min": 64}, {"xcd_aware": 0}, {"xcd_aware": 1, "refill_min": 8}, {"xcd_aware": 2, "refill_min0": 17}):
         c = np.zeros_like(a)
         R.HipRayCaster(seed=3, tuning=tn).walk_rays(vp, sp, c, 1, False)
         assert_bits_equal(a, c, f"tuning {tn}")
@@ -775,7 +775,8 @@ def test_octree_build_on_gpu_equals_oracle_build(which, canonical_pair, grid_pai
 def test_fused_and_per_pass_pipelines_same_image(canonical_pair, circles_pair):
     """The default pipeline renders an octree scene with the fused path kernels (k_path_primary: pixel_ray + closest hit +
     color_ray of the primary rays; k_path_bounce: every bounce of every path in one persistent launch, shaded in place);
-    tuning pipeline=1 runs the same frame with one launch per bounce pass (k_gen, k_trace_oct + k_shade per pass).  Same
+    tuning pipeline=1 runs the same frame with one launch per bounce pass (k_gen, k_trace_oct + k_shade per pass), pipeline=3
+    (the default) k_path_primary and then the bounce passes one launch each.  Same
     device functions, so: image bits, "Rays" and all work counters equal each other AND the oracle -- odd sizes, sample
     counts that are not powers of two (the path -> (pixel, sample) mapping divides by them), depth limits 1..7, batches
     smaller than a wave, refill thresholds 1..64, striped tiles."""
@@ -787,7 +788,7 @@ def test_fused_and_per_pass_pipelines_same_image(canonical_pair, circles_pair):
         vo, vp = _viewports(w, h, depth, spp)
         ref, cn = so.render(w, h, vo, depth, spp, seed=seed, threads=8)
         imgs = {}
-        for pipe in (1, 2):
+        for pipe in (1, 2, 3):
             img = np.zeros((h, w, 4), np.float32)
             ctx = R.HipRayCaster(seed=seed, options=R.OPT_COUNTERS, tuning={"pipeline": pipe}).walk_rays(vp, sp, img, 1, False)
             assert ctx.stats["pipeline"] == pipe
@@ -795,9 +796,9 @@ def test_fused_and_per_pass_pipelines_same_image(canonical_pair, circles_pair):
             for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
                 assert ctx.stats[k] == cn[k], (pipe, k)
             imgs[pipe] = img
-            assert ctx.stats["trace_launches"] == (depth if pipe == 1 else min(depth, 2)) * ctx.stats["streams"]
+            assert ctx.stats["trace_launches"] == (min(depth, 2) if pipe == 2 else depth) * ctx.stats["streams"]
         # uncounted kernels (the ones that are timed)
-        for pipe in (1, 2):
+        for pipe in (1, 2, 3):
             img = np.zeros((h, w, 4), np.float32)
             ctx = R.HipRayCaster(seed=seed, tuning={"pipeline": pipe}).walk_rays(vp, sp, img, 1, False)
             assert_bits_equal(ref, img, f"uncounted pipeline {pipe}")
@@ -808,12 +809,13 @@ def test_fused_and_per_pass_pipelines_same_image(canonical_pair, circles_pair):
     vo, vp = _viewports(w, h, 5, spp)
     ref, cn = so.render(w, h, vo, 5, spp, seed=21, threads=8)
     for tun in ({"batch_paths": 40}, {"batch_paths": 1000, "streams": 2}, {"refill_min": 1, "refill_min0": 1}, {"refill_min": 64, "refill_min0": 64},
-                {"refill_min": 23, "refill_min0": 17, "streams": 4, "subtile_min_paths": 1}, {"oct_waves_per_cu": 1}, {"xcd_aware": 0},
+                {"refill_min": 23, "refill_min0": 17, "streams": 4, "subtile_min_paths": 1}, {"oct_waves_per_cu": 1}, {"xcd_aware": 1},
                 {"xcd_aware": 2, "streams": 1}):
         img = np.zeros((h, w, 4), np.float32)
-        ctx = R.HipRayCaster(seed=21, tuning=dict(tun, pipeline=2)).walk_rays(vp, sp, img, 1, False)
-        assert_bits_equal(ref, img, f"fused, tuning {tun}")
-        assert ctx.total_rays == cn["rays"], tun
+        for pipe in (2, 3):
+            ctx = R.HipRayCaster(seed=21, tuning=dict(tun, pipeline=pipe)).walk_rays(vp, sp, img, 1, False)
+            assert_bits_equal(ref, img, f"pipeline {pipe}, tuning {tun}")
+            assert ctx.total_rays == cn["rays"], (pipe, tun)
     # a striped tile (one rank of three) through the fused kernels equals those rows of the frame
     import torch
     from rust_raytrace_amd import dist as rd

@@ -19,7 +19,7 @@ for it in range(n):
     ref, cn = so.render(w, h, vo, depth, spp, seed=it, threads=8)
     tune = {"batch_paths": int(rng.integers(1, 4 * w * h * spp)), "streams": int(rng.integers(1, 5)), "subtile_min_paths": 1,
             "oct_waves_per_cu": int(rng.choice([0, 1, 3, 8, 16, 24, 32])), "refill_min0": int(rng.integers(1, 65)),
-            "refill_min": int(rng.integers(1, 65)), "xcd_aware": int(rng.integers(0, 3))}
+            "refill_min": int(rng.integers(1, 65)), "xcd_aware": int(rng.integers(0, 3)), "pipeline": int(rng.integers(1, 4))}
     img = np.zeros((h, w, 4), np.float32)
     ctx = R.HipRayCaster(seed=it, tuning=tune).walk_rays(vp, sp, img, 1, False)
     assert_bits_equal(ref, img, f"{w}x{h} spp {spp} depth {depth} tuning {tune}")

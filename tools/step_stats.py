@@ -33,3 +33,6 @@ tot = max(d[11], 1)
 print(f"shader-clock cycles of a wave (counting build, all passes of the last batch): SELECT steps {d[8] / tot:.3f}, LEAF steps {d[9] / tot:.3f}, "
       f"refills {d[10] / tot:.3f}, vote/rest {1 - (d[8] + d[9] + d[10]) / tot:.3f} of the wave's lifetime; "
       f"{d[8] / max(d[0], 1):.0f} cycles per SELECT step, {d[9] / max(d[2], 1):.0f} per LEAF step, {d[10] / max(d[4], 1):.0f} per refill")
+print(f"t < 0 decidable from signs/exponents alone: {d[12]} of {ctx.stats['tri_tests']} plane tests of the last batch's lanes "
+      f"({d[12] / max(ctx.stats['tri_tests'], 1):.3f} if the call was one batch); wave level: {d[13]} of {d[14]} (LEAF step, reference) slots "
+      f"have EVERY working lane decidable ({d[13] / max(d[14], 1):.4f}); LEAF steps with all four slots so: {d[15]} of {d[2]} ({d[15] / max(d[2], 1):.4f})")
