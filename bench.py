@@ -286,34 +286,49 @@ def main():
 
 
 def roofline_object(args, caster, scene, vp, tile, local, stream, rays_per_frame, trace_ms, kernel_ms, launches, dt):
-    """Dominant kernel = the closest-hit kernel (k_trace_oct / k_trace_linear, ~97 % of device time).  It is bound by
-    FP32 VALU issue, not by HBM: the ~19 MB scene is served from L1/L2/Infinity Cache.  Everything here is recomputable
-    from the printed raw counters: flops = 15*box + 28*tri + 21*full, bytes = 16*box + 32*tri + 52*full."""
+    """Dominant kernel = the closest-hit kernel of the bounce passes (k_trace_oct, 4 launches per single-stream frame, ~2/3
+    of the device time; k_trace_linear for config 2); k_path_primary (pixel_ray + closest hit + color_ray of the primary
+    rays, one launch) is reported beside it.  Both are bound by FP32 VALU issue, not by HBM: the ~19 MB scene is served
+    from L1/L2/Infinity Cache.  Everything is recomputable from the printed raw counters: flops = 15*box + 28*tri + 21*full,
+    bytes = 16*box + 32*tri + 52*full.
+
+    ONE launch set for every per-launch figure: the frame rendered on a single internal stream (tuning streams = 1), where
+    each launch has the GPU to itself -- `achieved` (HIP events around the launches, measured here), `traffic` and the
+    VALU / clock figures (rocprofv3 --pmc of the same single-stream frame, profiles/pmc_latest.json)."""
     from rust_raytrace_amd import raytrace as R
     base_opts = caster.options
-    caster.options = base_opts | R.OPT_COUNTERS
-    cctx = caster.walk_tile_device(vp, scene, tile, local.data_ptr(), stream.cuda_stream)
-    caster.options = base_opts
-    st = cctx.stats
-    n_box, n_tri, n_full = st["box_tests"], st["tri_tests"], st["full_tests"]
-    flops = 15 * n_box + 28 * n_tri + 21 * n_full           # per frame (SURVEY 8d "algorithmic flops per unit")
-    alg_bytes = 16 * n_box + (4 + 28) * n_tri + 52 * n_full  # per frame (SURVEY 8d "algorithmic bytes per unit")
+    solo_tune = {"streams": 1}
+
+    def counted(v):
+        c = R.HipRayCaster(seed=caster.seed, device=caster.device, options=base_opts | R.OPT_COUNTERS, tuning=solo_tune)
+        return c.walk_tile_device(v, scene, tile, local.data_ptr(), stream.cuda_stream).stats
+
+    st = counted(vp)                                                # the whole frame
+    work = lambda q: (15 * q["box_tests"] + 28 * q["tri_tests"] + 21 * q["full_tests"],          # flops  (SURVEY 8d)
+                      16 * q["box_tests"] + (4 + 28) * q["tri_tests"] + 52 * q["full_tests"])   # bytes  (SURVEY 8d)
+    flops, alg_bytes = work(st)
+    # the primary rays alone: the same frame at maxdepth 1 (identical primary rays, nothing bounces)
+    vp1 = R.canonical_viewport(args.width, args.height, 1, args.spp)
+    st1 = counted(vp1)
+    flops_p, bytes_p = work(st1)
+    flops_b, bytes_b = flops - flops_p, alg_bytes - bytes_p
     frame_ms = kernel_ms / args.steps                          # device time span of one frame in the timed region
     chip = flops / (frame_ms * 1e-3) / 1e12
-    # Per-launch duration of the dominant kernel, measured live with HIP events on its launch stream.  In the timed
-    # region the sub-tiles run on their own streams and their launches share the GPU, which stretches every launch; so the
-    # kernel is also run ALONE here: one frame on a single internal stream (tuning streams = 1), one launch per pass.
-    from rust_raytrace_amd import raytrace as R2
-    solo = R2.HipRayCaster(seed=caster.seed, device=caster.device, options=base_opts, tuning={"streams": 1})
+    # per-launch durations, measured live with HIP events on the launch stream, kernel alone on the GPU (one stream)
+    solo = R.HipRayCaster(seed=caster.seed, device=caster.device, options=base_opts, tuning=solo_tune)
     solo.walk_tile_device(vp, scene, tile, local.data_ptr(), stream.cuda_stream)
-    sctx = solo.walk_tile_device(vp, scene, tile, local.data_ptr(), stream.cuda_stream)
-    n_launch_frame = max(sctx.stats["trace_launches"], 1)
-    avg_launch_ms = sctx.stats["trace_ms"] / n_launch_frame
-    solo_frame_ms = sctx.stats["kernel_ms"]
-    achieved = flops / n_launch_frame / (avg_launch_ms * 1e-3) / 1e12
-    shared_launch_ms = trace_ms / max(launches, 1)             # the same per launch in the timed region (several streams)
-    # measured fabric traffic and VALU issue rate: from the committed rocprofv3 --pmc passes of this config (a profile
-    # is a separate run: rocprofv3 cannot run inside bench.py); null when the workload is not the profiled one
+    ss = solo.walk_tile_device(vp, scene, tile, local.data_ptr(), stream.cuda_stream).stats
+    split = ss["pipeline"] != 1 and ss["primary_ms"] > 0       # the primary rays have their own kernel
+    n_launch_frame = max(ss["trace_launches"], 1)
+    if split:
+        n_dom = max(n_launch_frame - 1, 1)
+        dom_ms, dom_flops, dom_bytes = ss["bounce_ms"] / n_dom, flops_b / n_dom, bytes_b / n_dom
+    else:
+        n_dom = n_launch_frame
+        dom_ms, dom_flops, dom_bytes = ss["trace_ms"] / n_dom, flops / n_dom, alg_bytes / n_dom
+    achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+    kernel = {"linear": "k_trace_linear"}.get(args.scene, "k_trace_oct")
+    # rocprofv3 --pmc passes of the single-stream frame (a profile is a separate run: rocprofv3 cannot run inside bench.py)
     prof = None
     pj = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pj):
@@ -322,44 +337,64 @@ def roofline_object(args, caster, scene, vp, tile, local, stream, rays_per_frame
         except Exception:
             prof = None
     same_cfg = bool(prof) and prof.get("config") == {"scene": args.scene, "width": args.width, "height": args.height, "spp": args.spp, "fast": bool(args.fast)}
-    traffic = prof.get("fabric_bytes_per_launch") if same_cfg else None
-    # chip VALU issue capacity: 256 CUs x 4 SIMDs, one wave64 instruction per 2 cycles, at the 2.4 GHz maximum clock
-    valu_issue_peak = 256 * 4 * 2.4e9 / 2.0
-    kernel = "k_trace_oct" if args.scene != "linear" else "k_trace_linear"
+    pk = (prof.get("kernels", {}).get(kernel) if same_cfg else None) or None
+    traffic = pk.get("fabric_bytes_per_launch") if pk else None
+    other = None
+    if split:
+        pp = (prof.get("kernels", {}).get("k_path_primary") if same_cfg else None) or {}
+        a_p = flops_p / (ss["primary_ms"] * 1e-3) / 1e12
+        other = {"kernel": "k_path_primary", "launches_per_frame": 1, "avg_launch_ms": round(ss["primary_ms"], 3),
+                 "achieved_TFLOPs": round(a_p, 3), "frac": round(a_p / FP32_NOFMA_PEAK_TF, 4),
+                 "Grays_per_s": round(st1["rays"] / ss["primary_ms"] / 1e6, 3), "traffic": pp.get("fabric_bytes_per_launch"),
+                 "note": "its flops are those of the primary rays' closest hits only; pixel_ray (Philox + 2 unit()) and color_ray of every primary ray run in the same launch and are not counted"}
+
+    def issue(pkk, ms):  # VALU issue fraction of a kernel over its own duration: 256 CUs x 4 SIMDs, one wave64 instruction per 2 clocks
+        if not pkk or not pkk.get("valu_wave_insts_per_launch"):
+            return None
+        per_clock = pkk["valu_wave_insts_per_launch"] / (ms * 1e-3) / (256 * 4 / 2.0)
+        clk = pkk.get("effective_clock_GHz")
+        return {"valu_wave_insts_per_launch": pkk["valu_wave_insts_per_launch"], "valu_issue_frac_at_2.4GHz": round(per_clock / 2.4e9, 4),
+                "effective_clock_GHz": clk, "valu_issue_frac_at_held_clock": round(per_clock / (clk * 1e9), 4) if clk else None,
+                "valu_lane_utilisation": pkk.get("valu_lane_utilisation"), "wait_any_frac": pkk.get("wait_any_frac"), "l2_hit_rate": pkk.get("l2_hit_rate")}
+
+    rays_b = st["rays"] - st1["rays"]
     return {
         "bound": "valu", "kernel": kernel, "unit": "TFLOP/s",
         "achieved": round(achieved, 3), "peak": FP32_NOFMA_PEAK_TF, "frac": round(achieved / FP32_NOFMA_PEAK_TF, 4),
         "traffic": traffic,
-        "raw": {"rays": st["rays"], "box_tests": n_box, "tri_tests": n_tri, "full_tests": n_full, "nodes": st["nodes"],
-                "leaves": st["leaves"], "trace_launches_per_frame": n_launch_frame, "avg_launch_ms": round(avg_launch_ms, 3),
-                "single_stream_frame_device_ms": round(solo_frame_ms, 3),
-                "timed_region": {"frame_device_ms": round(frame_ms, 3), "streams": int(st.get("streams", 1)),
-                                 "launches_per_frame": int(launches / args.steps), "avg_launch_ms_sharing_the_gpu": round(shared_launch_ms, 3)}},
-        "per_ray": {"box_tests": round(n_box / max(st["rays"], 1), 1), "tri_tests": round(n_tri / max(st["rays"], 1), 1),
-                    "full_tests": round(n_full / max(st["rays"], 1), 2), "flops": round(flops / max(st["rays"], 1)),
-                    "algorithmic_bytes": round(alg_bytes / max(st["rays"], 1))},
+        "launch_set": f"single-stream frame: {n_dom} x {kernel}" + (" (bounce passes) + 1 x k_path_primary" if split else "") + "; achieved, traffic and issue figures are per launch of THIS set",
+        "raw": {"rays": st["rays"], "box_tests": st["box_tests"], "tri_tests": st["tri_tests"], "full_tests": st["full_tests"], "nodes": st["nodes"],
+                "leaves": st["leaves"], "primary_only": {k: st1[k] for k in ("rays", "box_tests", "tri_tests", "full_tests")},
+                "launches_per_frame": n_dom, "avg_launch_ms": round(dom_ms, 3), "flops_per_launch": int(dom_flops),
+                "algorithmic_bytes_per_launch": int(dom_bytes), "rays_in_these_launches": int(rays_b if split else st["rays"]),
+                "single_stream_frame_device_ms": round(ss["kernel_ms"], 3), "pipeline": ss["pipeline"],
+                "timed_region": {"frame_device_ms": round(frame_ms, 3), "launches_per_frame": int(launches / args.steps), "avg_launch_ms_sharing_the_gpu": round(trace_ms / max(launches, 1), 3)}},
+        "per_ray": {"box_tests": round(st["box_tests"] / max(st["rays"], 1), 1), "tri_tests": round(st["tri_tests"] / max(st["rays"], 1), 1),
+                    "full_tests": round(st["full_tests"] / max(st["rays"], 1), 2), "flops": round(flops / max(st["rays"], 1)),
+                    "algorithmic_bytes": round(alg_bytes / max(st["rays"], 1)),
+                    "bounce_rays": {"flops": round(flops_b / max(rays_b, 1)), "algorithmic_bytes": round(bytes_b / max(rays_b, 1))} if split else None},
+        "other_kernel": other,
         "fractions": {
-            "i_algorithmic_bytes_GBs_vs_hbm_peak": {"achieved": round(alg_bytes / (frame_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                                    "ratio": round(alg_bytes / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "i_algorithmic_bytes_GBs_vs_hbm_peak": {"achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                                    "ratio": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                    "frame": round(alg_bytes / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                     "note": "cache-served, NOT a bound: child boxes are implicit and the scene sits in L2/Infinity Cache, so this ratio may exceed 1"},
             "ii_fp32_TFLOPs": {"per_launch": round(achieved, 3), "chip_frame": round(chip, 3), "peak_no_fma": FP32_NOFMA_PEAK_TF,
                                "frac_no_fma_chip": round(chip / FP32_NOFMA_PEAK_TF, 4), "peak_fma": FP32_FMA_PEAK_TF,
                                "frac_fma_chip": round(chip / FP32_FMA_PEAK_TF, 4)},
-            "iii_measured_fabric_GBs": ({"achieved": round(prof["fabric_bytes_per_frame"] / (frame_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                         "ratio": round(prof["fabric_bytes_per_frame"] / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                         "fabric_bytes_per_frame": prof["fabric_bytes_per_frame"],
-                                         "valu_wave_insts_per_frame": prof.get("valu_wave_insts_per_frame"),
-                                         "valu_issue_frac_at_2.4GHz": (round(prof["valu_wave_insts_per_frame"] / (frame_ms * 1e-3) / valu_issue_peak, 4)
-                                                                       if prof.get("valu_wave_insts_per_frame") else None),
-                                         "valu_lane_utilisation": prof.get("valu_lane_utilisation"),
-                                         "source": prof.get("source"), "profiled_commit": prof.get("commit"),
-                                         "note": "counters from the committed profile of this workload (profiles/pmc_latest.json), "
-                                                 "rates against THIS run's frame time"} if same_cfg else None),
+            "iii_measured": ({"fabric_GBs": round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic else None, "hbm_peak_GBs": HBM_PEAK_GBS,
+                              "fabric_ratio": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                              "traffic_over_algorithmic_bytes": round(traffic / dom_bytes, 4) if traffic else None,
+                              kernel: issue(pk, dom_ms),
+                              "k_path_primary": issue(prof.get("kernels", {}).get("k_path_primary"), ss["primary_ms"]) if split else None,
+                              "source": prof.get("source"), "profiled_commit": prof.get("commit"),
+                              "note": "counters from the committed single-stream profile of this workload (profiles/pmc_latest.json), per launch; "
+                                      "rates against THIS run's single-stream launch durations"} if pk else None),
         },
-        "note": "achieved = algorithmic FP32 flops of ONE closest-hit launch (device counters of a counting pass / launches per frame) / "
-                "its average HIP-event duration with the kernel alone on the GPU (one internal stream; this is what rocprofv3 "
-                "--kernel-trace of RTMI_STREAMS=1 reports, profiles/); peak = 157.3/2 TFLOP/s because a*b+c may not be contracted "
-                "(bit parity).  The timed region runs the sub-tiles on their own streams, whose launches overlap: chip_frame prices a frame's "
+        "note": "achieved = algorithmic FP32 flops of ONE launch of the dominant kernel (device counters of a counting pass: the frame's minus "
+                "the primary rays', / launches) / its average HIP-event duration with the kernel alone on the GPU (single-stream frame; what "
+                "rocprofv3 --kernel-trace of RTMI_STREAMS=1 lists, profiles/); peak = 157.3/2 TFLOP/s because a*b+c may not be contracted "
+                "(bit parity).  The timed region runs three sub-tiles on their own streams, whose launches overlap: chip_frame prices a frame's "
                 "flops against the frame's device time there.",
     }
 

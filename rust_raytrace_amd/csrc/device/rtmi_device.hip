@@ -516,24 +516,48 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed
     }
 }
 
-// walk_ray_set's per-pixel accumulation (raytrace.rs:1414-1426)
+// walk_ray_set's per-pixel accumulation (raytrace.rs:1414-1426): acc = 0; acc += sample_i in sample order; * (1/spp).
+// The sample colours of a pixel are consecutive in `scol` ([pixel][sample]), so one thread per pixel would read 16 B at a
+// stride of spp * 16 B (round 2: 5.9 x the bytes fetched, 128-B lines evicted between a thread's iterations).  Instead a
+// block takes RTMI_ACC_PIX consecutive pixels, streams their samples through LDS in chunks with fully coalesced float4
+// loads, and thread (pixel j, channel c) adds its pixel's samples of the chunk in order, keeping the running sum in a
+// register across chunks -- the same sequence of f32 additions per channel as the reference's Vec3 adds.  One float4 of
+// padding per 64 keeps the 16 pixels that are summed at a time (spp = 64) on different LDS banks.
 // `out` is the caller's tile buffer; the sub-tile `sub` of `nsub` holds every nsub-th stripe (S rows) of that tile, so
 // local row lr of the sub-tile is row ((lr / S) * nsub + sub) * S + lr % S of the buffer.
+#define RTMI_ACC_PIX 64
+#define RTMI_ACC_CHUNK 1024
 __global__ void __launch_bounds__(256) k_accum(uint32_t npixels, uint32_t spp, const float4* __restrict__ scol,
-                                               float4* __restrict__ out, uint32_t pix0, uint32_t W, uint32_t S, uint32_t nsub,
-                                               uint32_t sub) {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < npixels; p += stride) {
-        V4 acc = mk(0.f, 0.f, 0.f);
-        for (uint32_t s = 0; s < spp; s++) {
-            const float4 c = scol[(size_t)p * spp + s];
-            acc = vadd(acc, V4{c.x, c.y, c.z, c.w});
+                                               float* __restrict__ out, uint32_t pix0, uint32_t W, uint32_t S, uint32_t nsub,
+                                               uint32_t sub, FastDiv dW, FastDiv dS) {
+    __shared__ float4 stage[RTMI_ACC_CHUNK + RTMI_ACC_CHUNK / 64 + 1];
+    const float* stage_f = reinterpret_cast<const float*>(stage);
+    const uint32_t tid = threadIdx.x, j = tid >> 2, c = tid & 3u;
+    const float inv = 1.f / (float)spp;
+    for (uint32_t pb = blockIdx.x * RTMI_ACC_PIX; pb < npixels; pb += gridDim.x * RTMI_ACC_PIX) {
+        const uint32_t npb = min((uint32_t)RTMI_ACC_PIX, npixels - pb);
+        const uint32_t f0 = pb * spp, f1 = f0 + npb * spp;       // the block's samples: scol[f0 .. f1)
+        const uint32_t my0 = f0 + j * spp, my1 = my0 + spp;      // this thread's pixel (when j < npb)
+        float acc = 0.f;
+        for (uint32_t ch = f0; ch < f1; ch += RTMI_ACC_CHUNK) {
+            const uint32_t n = min((uint32_t)RTMI_ACC_CHUNK, f1 - ch);
+            __syncthreads();  // the previous chunk has been consumed
+            for (uint32_t k = tid; k < n; k += 256u) stage[k + (k >> 6)] = scol[ch + k];
+            __syncthreads();
+            if (j < npb) {
+                const uint32_t lo = max(my0, ch), hi = min(my1, ch + n);
+                for (uint32_t s = lo; s < hi; s++) {
+                    const uint32_t k = s - ch;
+                    acc = acc + stage_f[(k + (k >> 6)) * 4u + c];
+                }
+            }
         }
-        const V4 px = vmul(acc, 1.f / (float)spp);
-        const uint32_t lp = pix0 + p, lr = lp / W, col = lp - lr * W;
-        const uint32_t k = lr / S;
-        const size_t orow = (size_t)(k * nsub + sub) * S + (lr - k * S);
-        out[orow * W + col] = make_float4(px.x, px.y, px.z, px.w);
+        if (j < npb) {
+            const uint32_t lp = pix0 + pb + j, lr = fdiv(lp, dW), col = lp - lr * W;
+            const uint32_t k = fdiv(lr, dS);
+            const size_t orow = (size_t)(k * nsub + sub) * S + (lr - k * S);
+            out[(orow * W + col) * 4u + c] = acc * inv;
+        }
     }
 }
 
@@ -1381,7 +1405,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
                 launches++;
             }
             }
-            hipLaunchKernelGGL(k_accum, dim3(ew_blocks), dim3(256), 0, st, np, spp, w.scol.p, out, pix0, W, S, nsub, t);
+            hipLaunchKernelGGL(k_accum, dim3(ew_blocks), dim3(256), 0, st, np, spp, w.scol.p, (float*)out, pix0, W, S, nsub, t, make_fastdiv(W), make_fastdiv(S));
             HIPCHK(hipEventRecord(w.ev[1], st));
             HIPCHK(hipGetLastError());
         }

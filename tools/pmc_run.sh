@@ -1,6 +1,9 @@
 #!/bin/bash
 # usage: RTMI_COMMIT=<sha> [RTMI_PMC_CONFIG='{json}'] tools/pmc_run.sh <tag> <bench args...>   (run on the GPU box through gpurun)
 # Separate rocprofv3 --pmc passes (no tracing domains combined with counters), CSV output under gpurun_out/.
+# The profiled frame runs on ONE internal stream (RTMI_STREAMS=1): every launch has the GPU to itself, the launch set bench.py's
+# roofline object times.
+export RTMI_STREAMS=1
 tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 mkdir -p $out
