@@ -94,6 +94,8 @@ typedef struct rtmi_stats {
                              * same device); 0 = the runtime refused: the band is staged (rtmi_last_error() carries a
                              * warning although the call returns RTMI_OK)                                      */
     uint32_t pipeline;      /* which pipeline rendered (rtmi_tuning_t.pipeline: 1, 2 or 3)                         */
+    uint32_t slow_paths;    /* paths handed to k_path_slow (rtmi_tuning_t.slow_path_off)                           */
+    uint32_t reserved;
 } rtmi_stats_t;
 
 /* A set of image rows: `nrows` rows taken in stripes of `stripe_rows`
@@ -187,7 +189,12 @@ typedef struct rtmi_tuning {
                                  * one closest-hit + one shading launch per bounce pass.  2 and 3 apply to octree scenes;
                                  * anything else (linear list, generic tree, BVH mode, analytic spheres) runs 1.
                                  * Same image whichever runs.  Environment: RTMI_PIPELINE.                              */
-    uint32_t reserved;
+    uint32_t slow_path_off;     /* 0 (default): in pipelines 2 and 3 a ray whose unit direction has an exactly-zero component
+                                 * (BoundingBox::collides then skips that axis' slab, raytrace.rs:872-900: ~150 x the work of an
+                                 * ordinary ray, 14 ms for the lane that traces it) is set aside and its path is traced by
+                                 * k_path_slow on a side stream, one path per wave, beside the following passes; 1: such rays
+                                 * are traced where they arise (they can hold a small tile's launches for ~10 % of its time).
+                                 * Environment: RTMI_SLOW_PATH_OFF.                                                    */
 } rtmi_tuning_t;
 int rtmi_scene_get_tuning(rtmi_scene_t* scene, rtmi_tuning_t* out);
 int rtmi_scene_set_tuning(rtmi_scene_t* scene, const rtmi_tuning_t* in);

@@ -19,7 +19,7 @@ class Stats(C.Structure):
                 ("kernel_ms", C.c_double), ("trace_ms", C.c_double), ("trace_launches", C.c_uint32),
                 ("streams", C.c_uint32), ("render_ms", C.c_double), ("band_copy_ms", C.c_double),
                 ("deinterleave_ms", C.c_double), ("primary_ms", C.c_double), ("bounce_ms", C.c_double),
-                ("peer_access", C.c_int32), ("pipeline", C.c_uint32)]
+                ("peer_access", C.c_int32), ("pipeline", C.c_uint32), ("slow_paths", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -34,7 +34,7 @@ class Tuning(C.Structure):
     """rtmi_tuning_t (include/rtmi.h)."""
     _fields_ = [("batch_paths", C.c_uint64), ("streams", C.c_uint32), ("subtile_min_paths", C.c_uint32),
                 ("oct_waves_per_cu", C.c_uint32), ("refill_min0", C.c_uint32), ("refill_min", C.c_uint32),
-                ("xcd_aware", C.c_uint32), ("kernel", C.c_uint32), ("pipeline", C.c_uint32), ("reserved", C.c_uint32)]
+                ("xcd_aware", C.c_uint32), ("kernel", C.c_uint32), ("pipeline", C.c_uint32), ("slow_path_off", C.c_uint32)]
 
 
 def build(force=False):

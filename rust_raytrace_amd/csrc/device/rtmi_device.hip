@@ -38,7 +38,7 @@
 #include "vec4.hpp"
 
 // layouts the language bindings mirror (rust_raytrace_amd/_ffi.py, INTEGRATION.md ffi.rs; tests/test_host_cpu.py)
-static_assert(sizeof(rtmi_stats_t) == 120 && sizeof(rtmi_tuning_t) == 48 && sizeof(rtmi_tile_t) == 16 && sizeof(rtmi_box_t) == 32 &&
+static_assert(sizeof(rtmi_stats_t) == 128 && sizeof(rtmi_tuning_t) == 48 && sizeof(rtmi_tile_t) == 16 && sizeof(rtmi_box_t) == 32 &&
               sizeof(rtmi_triangle_t) == 104 && sizeof(rtmi_viewport_t) == 64 && sizeof(rtmi_sphere_t) == 40, "ABI struct layout changed");
 
 namespace rtmi {
@@ -72,6 +72,7 @@ struct DScene {
     uint32_t nspheres;
     float root_half;
     uint32_t olevels;
+    uint32_t noblocks;  // reference blocks in `oblocks`
 };
 #define RTMI_FN_WIDE 0x10000u
 
@@ -83,10 +84,41 @@ struct DCtrl {
     uint32_t count[RTMI_MAX_PASSES + 1];  // rays queued for pass k
     uint32_t head[RTMI_MAX_PASSES + 1];   // work-fetch cursor of pass k
     uint32_t xhead[RTMI_MAX_PASSES + 1][8];  // octree kernel: one cursor per XCD range of the queue
+    // slow-path queue (rays with an exactly-zero direction component, trace_oct.hpp): entries pushed so far, and per
+    // consumer launch k its range [slo[k], shi[k]) (k_slow_snapshot) and work-fetch cursor
+    uint32_t scount;
+    uint32_t slo[RTMI_MAX_PASSES + 1], shi[RTMI_MAX_PASSES + 1], shead[RTMI_MAX_PASSES + 1];
     unsigned long long rays;              // sum of count[] (the "Rays" statistic)
     unsigned long long counters[5];       // box_tests tri_tests full_tests nodes leaves
     unsigned long long dbg[16];           // step statistics of the counting build (tools/step_stats.py)
 };
+
+// The slow-path queue of one stream's batch.  A ray whose unit direction has an exactly-zero component skips that axis'
+// slab in BoundingBox::collides (raytrace.rs:872, :882, :892: the origin is not checked against the slab), so it enters
+// every box of the perpendicular plane: ~150 x the work of an ordinary ray (6 000 box + 36 000 triangle tests on the
+// canonical scene), 14 ms for the one lane that traces it.  78 of the 268 M primary rays of config 3 are such rays (the
+// two pixel rows and columns next to the camera axis, where `row + v_off` rounds to the axis), ~20 bounce rays per frame.
+// Their work is nothing, their LATENCY is: a lane that meets one near the end of a launch holds the launch (and, in the
+// primary pass, its whole wave) for up to 14 ms -- 10 % of a 1/8-frame tile.  Producers (k_path_primary, k_shade) put such
+// rays here instead of the ordinary queue; k_path_slow traces their paths to the end on a side stream, one path per
+// wave, concurrently with the following passes.  Same device functions, same image.
+struct SlowQ {
+    float4* o; float4* d; uint32_t* path; uint32_t* bounce;
+    uint32_t cap;
+};
+#define RTMI_SLOW_CAP 16384u
+__device__ inline bool has_zero_component(float x, float y, float z) { return (x == 0.f) | (y == 0.f) | (z == 0.f); }
+// true when the ray was queued for the slow path (false: the queue is full, the caller keeps the ray)
+__device__ inline bool slow_push(const SlowQ& q, DCtrl* ctrl, float4 o, float4 d, uint32_t path, uint32_t bounce) {
+    const uint32_t slot = atomicAdd(&ctrl->scount, 1u);
+    if (slot >= q.cap) return false;
+    q.o[slot] = o; q.d[slot] = d; q.path[slot] = path; q.bounce[slot] = bounce;
+    return true;
+}
+__global__ void k_slow_snapshot(DCtrl* ctrl, uint32_t k, uint32_t cap) {
+    ctrl->slo[k] = k ? ctrl->shi[k - 1] : 0u;
+    ctrl->shi[k] = min(ctrl->scount, cap);
+}
 
 // ---------------------------------------------------------------- ray for the hot loops
 struct RayK {
@@ -479,7 +511,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed
                                                const float* __restrict__ hit_t, float4* __restrict__ qo_n,
                                                float4* __restrict__ qd_n, uint32_t* __restrict__ qpath_n,
                                                uint16_t* __restrict__ mstack, float4* __restrict__ scol,
-                                               DCtrl* __restrict__ ctrl) {
+                                               DCtrl* __restrict__ ctrl, SlowQ slow) {
     const uint32_t count = ctrl->count[pass];
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -499,6 +531,11 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed
             path_pixel(v, pix0, path, prow, pcol, sample);
             push = shade_hit(sc, v.maxdepth, seed, npaths, path, prow * v.width + pcol, sample, (uint32_t)pass, tf, t,
                              V4{o4.x, o4.y, o4.z, o4.w}, V4{d4.x, d4.y, d4.z, d4.w}, mstack, scol, nr);
+            // a bounce ray with an exactly-zero direction component goes to the slow path (SlowQ), not to the next pass
+            if (push && slow.cap && has_zero_component(nr.dir.x, nr.dir.y, nr.dir.z) &&
+                slow_push(slow, ctrl, make_float4(nr.orig.x, nr.orig.y, nr.orig.z, nr.orig.w), make_float4(nr.dir.x, nr.dir.y, nr.dir.z, nr.dir.w),
+                          path, (uint32_t)pass + 1u))
+                push = false;
         }
         // compact surviving rays into the next queue: ballot + prefix sum, one atomic per wave
         const unsigned long long mask = __ballot(push);
@@ -523,13 +560,13 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed
 // loads, and thread (pixel j, channel c) adds its pixel's samples of the chunk in order, keeping the running sum in a
 // register across chunks -- the same sequence of f32 additions per channel as the reference's Vec3 adds.  One float4 of
 // padding per 64 keeps the 16 pixels that are summed at a time (spp = 64) on different LDS banks.
-// `out` is the caller's tile buffer; the sub-tile `sub` of `nsub` holds every nsub-th stripe (S rows) of that tile, so
-// local row lr of the sub-tile is row ((lr / S) * nsub + sub) * S + lr % S of the buffer.
+// `out` is the caller's tile buffer; the sub-tile `sub` of `nsub` holds every nsub-th ROW of that tile, so local row lr of
+// the sub-tile is row lr * nsub + sub of the buffer.
 #define RTMI_ACC_PIX 64
 #define RTMI_ACC_CHUNK 1024
 __global__ void __launch_bounds__(256) k_accum(uint32_t npixels, uint32_t spp, const float4* __restrict__ scol,
-                                               float* __restrict__ out, uint32_t pix0, uint32_t W, uint32_t S, uint32_t nsub,
-                                               uint32_t sub, FastDiv dW, FastDiv dS) {
+                                               float* __restrict__ out, uint32_t pix0, uint32_t W, uint32_t nsub, uint32_t sub,
+                                               FastDiv dW) {
     __shared__ float4 stage[RTMI_ACC_CHUNK + RTMI_ACC_CHUNK / 64 + 1];
     const float* stage_f = reinterpret_cast<const float*>(stage);
     const uint32_t tid = threadIdx.x, j = tid >> 2, c = tid & 3u;
@@ -554,8 +591,7 @@ __global__ void __launch_bounds__(256) k_accum(uint32_t npixels, uint32_t spp, c
         }
         if (j < npb) {
             const uint32_t lp = pix0 + pb + j, lr = fdiv(lp, dW), col = lp - lr * W;
-            const uint32_t k = fdiv(lr, dS);
-            const size_t orow = (size_t)(k * nsub + sub) * S + (lr - k * S);
+            const size_t orow = (size_t)lr * nsub + sub;
             out[(orow * W + col) * 4u + c] = acc * inv;
         }
     }
@@ -682,6 +718,12 @@ struct Work {
     DevBuf<float> hit_t;
     DevBuf<uint16_t> mstack;
     DevBuf<DCtrl> ctrl;
+    // slow path (SlowQ): its queue, the side stream its consumer launches run on, "producer k done" / "slow path done" events
+    DevBuf<float4> sqo, sqd;
+    DevBuf<uint32_t> sqpath, sqbounce;
+    hipStream_t sstream = nullptr;
+    std::vector<hipEvent_t> sev;
+    hipEvent_t sdone = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> pass_ev;  // start/stop of the trace kernel of every pass
     void release() {
@@ -690,6 +732,11 @@ struct Work {
         for (int k = 0; k < 2; k++) if (ev[k]) { (void)hipEventDestroy(ev[k]); ev[k] = nullptr; }
         for (hipEvent_t e : pass_ev) (void)hipEventDestroy(e);
         pass_ev.clear();
+        sqo.release(); sqd.release(); sqpath.release(); sqbounce.release();
+        for (hipEvent_t e : sev) (void)hipEventDestroy(e);
+        sev.clear();
+        if (sdone) { (void)hipEventDestroy(sdone); sdone = nullptr; }
+        if (sstream) { (void)hipStreamDestroy(sstream); sstream = nullptr; }
         cap = 0; cap_depth = 0; full = false;
     }
 };
@@ -945,6 +992,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     s->tune.xcd_aware = (uint32_t)(env_size("RTMI_XCD_AWARE", 0) % 3);
     s->tune.kernel = (uint32_t)std::min<size_t>(env_size("RTMI_KERNEL", 0), 2);
     s->tune.pipeline = (uint32_t)std::min<size_t>(env_size("RTMI_PIPELINE", 0), 3);
+    s->tune.slow_path_off = (uint32_t)std::min<size_t>(env_size("RTMI_SLOW_PATH_OFF", 0), 1);
     s->verbose = getenv("RTMI_VERBOSE") != nullptr;
     s->trace_block = block;
     s->trace_lds = (size_t)levels * 16 * block;
@@ -979,7 +1027,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     if (e != hipSuccess) return fail(hip_code(e), std::string("scene upload: ") + hipGetErrorString(e));
     s->d = DScene{s->nodes.p, s->refs.p, s->tplane.p, s->tedge.p, s->mats.p,
                   (uint32_t)nboxes, (uint32_t)ntris, (uint32_t)matmap.size(), levels,
-                  s->octree ? s->fnodes.p : nullptr, s->octree ? s->oblocks.p : nullptr, s->octree ? s->wlinks.p : nullptr, nullptr, 0u, boxes[0].len2, max_inner_depth + 1};
+                  s->octree ? s->fnodes.p : nullptr, s->octree ? s->oblocks.p : nullptr, s->octree ? s->wlinks.p : nullptr, nullptr, 0u, boxes[0].len2, max_inner_depth + 1, (uint32_t)hob.size()};
     s->hmats = hm;
     if (s->octree) {
         s->oct_lds = (size_t)std::max<uint32_t>(1u, max_inner_depth) * 8 * 64;  // 2 words per level per lane
@@ -1094,7 +1142,7 @@ int rtmi_scene_get_tuning(rtmi_scene_t* s, rtmi_tuning_t* out) {
 int rtmi_scene_set_tuning(rtmi_scene_t* s, const rtmi_tuning_t* in) {
     if (!s || !in) return fail(RTMI_ERR_INVALID, "NULL argument");
     if (in->batch_paths == 0 || in->streams < 1 || in->streams > RTMI_MAX_STREAMS || in->oct_waves_per_cu > 32 || in->refill_min0 < 1 ||
-        in->refill_min0 > 64 || in->refill_min < 1 || in->refill_min > 64 || in->xcd_aware > 2 || in->kernel > 2 || in->pipeline > 3)
+        in->refill_min0 > 64 || in->refill_min < 1 || in->refill_min > 64 || in->xcd_aware > 2 || in->kernel > 2 || in->pipeline > 3 || in->slow_path_off > 1)
         return fail(RTMI_ERR_INVALID, "tuning value out of range");
     s->tune = *in;
     return RTMI_OK;
@@ -1119,6 +1167,22 @@ static int ensure_workspace(Work& w, size_t cap, uint32_t maxdepth, bool fused) 
     }
     w.full = full;
     HIPCHK(w.mstack.ensure(cap * (size_t)maxdepth));
+    HIPCHK(w.sqo.ensure(RTMI_SLOW_CAP)); HIPCHK(w.sqd.ensure(RTMI_SLOW_CAP));
+    HIPCHK(w.sqpath.ensure(RTMI_SLOW_CAP)); HIPCHK(w.sqbounce.ensure(RTMI_SLOW_CAP));
+    if (!w.sstream) {
+        // highest priority: the persistent kernels of the ordinary passes never yield their wave slots, so the slow path's
+        // blocks must be first in line whenever slots come free (the end of the producer launch), not behind the queued
+        // blocks of the other streams' launches
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        HIPCHK(hipStreamCreateWithPriority(&w.sstream, hipStreamNonBlocking, hi));
+    }
+    if (!w.sdone) HIPCHK(hipEventCreateWithFlags(&w.sdone, hipEventDisableTiming));
+    while (w.sev.size() < (size_t)std::max<uint32_t>(maxdepth, 2u)) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        w.sev.push_back(e);
+    }
     while (w.pass_ev.size() < 2 * (size_t)std::max<uint32_t>(maxdepth, 2u)) {
         hipEvent_t e;
         HIPCHK(hipEventCreate(&e));
@@ -1180,7 +1244,12 @@ static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* q
     if (s->d.nspheres)  // analytic spheres: a flat list against every ray, after the tree (not part of the timed trace kernel)
         hipLaunchKernelGGL(k_trace_spheres, dim3((unsigned)(s->num_cu * 8)), dim3(256), 0, st, s->d, qo, qd, w.ctrl.p, pass, w.hit_tf.p, w.hit_t.p);
 }
-// The fused path kernels (trace_oct.hpp): which = W_PRIMARY or W_BOUNCE.  `stop` is recorded right after the kernel.
+// where a stream's zero-component rays go; cap 0 (tuning slow_path = 0... or the queue not allocated) keeps them in place
+static SlowQ slow_queue(rtmi_scene* s, Work& w) {
+    const bool on = s->tune.slow_path_off == 0u && w.sqo.p && w.sstream;
+    return SlowQ{w.sqo.p, w.sqd.p, w.sqpath.p, w.sqbounce.p, on ? RTMI_SLOW_CAP : 0u};
+}
+// The fused path kernels (trace_oct.hpp): which = W_PRIMARY, W_BOUNCE or W_SLOW.  `stop` is recorded right after the kernel.
 template <bool COUNT>
 static void launch_path(rtmi_scene* s, Work& w, hipStream_t st, int which, const DView& dv, uint64_t seed, uint32_t pix0, uint32_t npaths,
                         hipEvent_t stop, int queue = 0) {
@@ -1191,9 +1260,21 @@ static void launch_path(rtmi_scene* s, Work& w, hipStream_t st, int which, const
     const int xcd = (int)(s->tune.xcd_aware % 3u);
     OctArgs a{};
     a.v = dv; a.seed = seed; a.pix0 = pix0; a.npaths = npaths;
-    a.bqo = w.qo[queue].p; a.bqd = w.qd[queue].p; a.bqpath = w.qpath[queue].p;
+    const int bq = which == W_SLOW ? 0 : queue;  // (for W_SLOW `queue` is the consumer launch number)
+    a.bqo = w.qo[bq].p; a.bqd = w.qd[bq].p; a.bqpath = w.qpath[bq].p;
     a.mstack = w.mstack.p; a.scol = w.scol.p;
+    a.slow = slow_queue(s, w);
     const bool fast = (s->options & RTMI_OPT_FAST) != 0;
+    if (which == W_SLOW) {
+        // consumer launch `queue` of the slow path, on the side stream: after the producer whose event is sev[queue]
+        a.slow_k = (uint32_t)queue;
+        (void)hipStreamWaitEvent(w.sstream, w.sev[queue], 0);
+        hipLaunchKernelGGL(k_slow_snapshot, dim3(1), dim3(1), 0, w.sstream, w.ctrl.p, (uint32_t)queue, a.slow.cap);
+        const dim3 sgrid((unsigned)(s->num_cu * 2));  // one path per wave at a time; a frame has ~100 such paths
+        if (fast) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_path_slow<COUNT, true>), sgrid, block, s->oct_lds, w.sstream, s->d, a, w.ctrl.p, 1, 0);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_path_slow<COUNT, false>), sgrid, block, s->oct_lds, w.sstream, s->d, a, w.ctrl.p, 1, 0);
+        return;
+    }
     if (which == W_PRIMARY) {
         if (fast) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_path_primary<COUNT, true>), grid, block, s->oct_lds, st, s->d, a, w.ctrl.p, refill, xcd);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_path_primary<COUNT, false>), grid, block, s->oct_lds, st, s->d, a, w.ctrl.p, refill, xcd);
@@ -1214,6 +1295,7 @@ static int read_stats(Work& w, hipStream_t st, rtmi_stats_t* stats, float kernel
         stats->box_tests += h.counters[0]; stats->tri_tests += h.counters[1]; stats->full_tests += h.counters[2];
         stats->nodes += h.counters[3]; stats->leaves += h.counters[4];
         stats->kernel_ms += kernel_ms; stats->trace_ms += trace_ms; stats->trace_launches += launches;
+        stats->slow_paths += std::min<uint32_t>(h.scount, RTMI_SLOW_CAP);
     }
     return RTMI_OK;
 }
@@ -1264,15 +1346,12 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
         return RTMI_OK;
     }
 
-    // ---- the caller's tile as stripes (a contiguous band is cut into <= 16-row stripes), split over the streams
-    uint32_t S = tile->stripe_rows, step = tile->stripe_step;
+    // ---- the tile's rows dealt out to the streams one row at a time (sub-tile t = rows t, t + nsub, ... of the tile): equal
+    //      shares whatever the tile's own striping is.  (Round 2 dealt out whole stripes: with the 16-row stripes of an
+    //      8-rank tiling a stream's stripes repeat every 384 image rows, the teapot covers two such periods and the slowest
+    //      stream of a rank carried up to 12 % more rays than the others.)
     uint32_t nsub = std::min<uint32_t>(std::max<uint32_t>(s->tune.streams, 1u), (uint32_t)RTMI_MAX_STREAMS);
-    if ((uint64_t)S >= nrows) {  // one stripe = contiguous band: at least one stripe per stream
-        S = std::min<uint32_t>(16u, std::max<uint32_t>(1u, (nrows + nsub - 1) / nsub));
-        step = S;
-    }
-    const uint32_t nstripes = (nrows + S - 1) / S;
-    nsub = std::min<uint32_t>(nsub, nstripes);
+    nsub = std::min<uint32_t>(nsub, nrows);
     if (npix * spp < s->tune.subtile_min_paths) nsub = 1;
     s->active_streams = nsub;
     SubTile sub[RTMI_MAX_STREAMS];
@@ -1283,11 +1362,10 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
         dv.vu = mk(vp->vu[0], vp->vu[1], vp->vu[2]);
         dv.vv = mk(vp->vv[0], vp->vv[1], vp->vv[2]);
         dv.width = W; dv.height = vp->height; dv.maxdepth = maxdepth; dv.spp = spp;
-        dv.row0 = row0 + t * step; dv.stripe_rows = S; dv.stripe_step = step * nsub; dv.pad = 0;
+        dv.row0 = row0; dv.stripe_rows = tile->stripe_rows; dv.stripe_step = tile->stripe_step; dv.pad = 0;
+        dv.sub_mul = nsub; dv.sub_off = t;
         view_set_divisors(dv);
-        uint64_t rows = 0;
-        for (uint32_t k = t; k < nstripes; k += nsub) rows += std::min<uint32_t>(S, nrows - k * S);
-        sub[t].npix = rows * W;
+        sub[t].npix = (uint64_t)((nrows - t + nsub - 1) / nsub) * W;
         sub[t].index = t;
     }
 
@@ -1347,6 +1425,16 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
                 else launch_path<false>(s, w, st, W_PRIMARY, dv, seed, pix0, npaths, w.pass_ev[1], 1);
                 HIPCHK(hipGetLastError());
                 launches++;
+                // the slow path (zero-component rays the producer set aside) runs beside the following passes
+                const bool slow_on = slow_queue(s, w).cap != 0u;
+                auto slow_after = [&](uint32_t k) {
+                    if (!slow_on) return;
+                    (void)hipEventRecord(w.sev[k], st);
+                    if (counting) launch_path<true>(s, w, st, W_SLOW, dv, seed, pix0, npaths, nullptr, (int)k);
+                    else launch_path<false>(s, w, st, W_SLOW, dv, seed, pix0, npaths, nullptr, (int)k);
+                };
+                slow_after(0);
+                HIPCHK(hipGetLastError());
                 for (uint32_t pass = 1; pass < maxdepth; pass++) {
                     const int a = pass & 1, b = a ^ 1;
                     HIPCHK(hipEventRecord(w.pass_ev[2 * pass], st));
@@ -1355,9 +1443,15 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
                     HIPCHK(hipGetLastError());
                     hipLaunchKernelGGL(k_shade, dim3(ew_blocks), dim3(256), 0, st, s->d, dv, seed, pix0, npaths, (int)pass,
                                        w.qo[a].p, w.qd[a].p, w.qpath[a].p, w.hit_tf.p, w.hit_t.p, w.qo[b].p, w.qd[b].p,
-                                       w.qpath[b].p, w.mstack.p, w.scol.p, w.ctrl.p);
+                                       w.qpath[b].p, w.mstack.p, w.scol.p, w.ctrl.p, slow_queue(s, w));
+                    HIPCHK(hipGetLastError());
+                    if (pass + 1 < maxdepth) slow_after(pass);  // the last pass's shading emits no rays
                     HIPCHK(hipGetLastError());
                     launches++;
+                }
+                if (slow_on) {  // the sample colours of the slow paths must be there before k_accum
+                    HIPCHK(hipEventRecord(w.sdone, w.sstream));
+                    HIPCHK(hipStreamWaitEvent(st, w.sdone, 0));
                 }
             } else if (fused) {
                 // primary rays generated, traced and shaded in one kernel; every bounce of every path in one more
@@ -1366,6 +1460,14 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
                 else launch_path<false>(s, w, st, W_PRIMARY, dv, seed, pix0, npaths, w.pass_ev[1]);
                 HIPCHK(hipGetLastError());  // a refused launch is reported where it happens, not at the end of the batch
                 launches++;
+                const bool slow_on = slow_queue(s, w).cap != 0u;
+                if (slow_on) {  // zero-component primary rays (and bounce rays of the primary hits): beside the bounce kernel
+                    (void)hipEventRecord(w.sev[0], st);
+                    if (counting) launch_path<true>(s, w, st, W_SLOW, dv, seed, pix0, npaths, nullptr, 0);
+                    else launch_path<false>(s, w, st, W_SLOW, dv, seed, pix0, npaths, nullptr, 0);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipEventRecord(w.sdone, w.sstream));
+                }
                 if (maxdepth > 1) {
                     HIPCHK(hipEventRecord(w.pass_ev[2], st));
                     if (counting) launch_path<true>(s, w, st, W_BOUNCE, dv, seed, pix0, npaths, w.pass_ev[3]);
@@ -1373,6 +1475,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
                     HIPCHK(hipGetLastError());
                     launches++;
                 }
+                if (slow_on) HIPCHK(hipStreamWaitEvent(st, w.sdone, 0));
             } else {
             hipLaunchKernelGGL(k_gen, dim3(ew_blocks), dim3(256), 0, st, dv, seed, pix0, npaths, w.qo[0].p, w.qd[0].p, w.qpath[0].p, w.ctrl.p);
             HIPCHK(hipGetLastError());  // a refused launch is reported where it happens, not at the end of the batch
@@ -1400,12 +1503,12 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
                 }
                 hipLaunchKernelGGL(k_shade, dim3(ew_blocks), dim3(256), 0, st, s->d, dv, seed, pix0, npaths, (int)pass,
                                    w.qo[a].p, w.qd[a].p, w.qpath[a].p, w.hit_tf.p, w.hit_t.p, w.qo[b].p, w.qd[b].p,
-                                   w.qpath[b].p, w.mstack.p, w.scol.p, w.ctrl.p);
+                                   w.qpath[b].p, w.mstack.p, w.scol.p, w.ctrl.p, SlowQ{nullptr, nullptr, nullptr, nullptr, 0u});
                 HIPCHK(hipGetLastError());
                 launches++;
             }
             }
-            hipLaunchKernelGGL(k_accum, dim3(ew_blocks), dim3(256), 0, st, np, spp, w.scol.p, (float*)out, pix0, W, S, nsub, t, make_fastdiv(W), make_fastdiv(S));
+            hipLaunchKernelGGL(k_accum, dim3(ew_blocks), dim3(256), 0, st, np, spp, w.scol.p, (float*)out, pix0, W, nsub, t, make_fastdiv(W));
             HIPCHK(hipEventRecord(w.ev[1], st));
             HIPCHK(hipGetLastError());
         }
@@ -1429,6 +1532,7 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
             if (stats) {
                 stats->rays += bs.rays; stats->box_tests += bs.box_tests; stats->tri_tests += bs.tri_tests;
                 stats->full_tests += bs.full_tests; stats->nodes += bs.nodes; stats->leaves += bs.leaves;
+                stats->slow_paths += bs.slow_paths;
             }
         }
     }

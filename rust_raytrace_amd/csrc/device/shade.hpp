@@ -31,7 +31,8 @@ __host__ __device__ inline uint32_t fdiv(uint32_t n, const FastDiv& f) {
 struct DView {
     V4 orig, cam, vu, vv;
     uint32_t width, height, maxdepth, spp;
-    uint32_t row0, stripe_rows, stripe_step, pad;  // rtmi_tile_t: which image rows the local rows are
+    uint32_t row0, stripe_rows, stripe_step, pad;  // rtmi_tile_t: which image rows the tile's rows are
+    uint32_t sub_mul, sub_off;                     // sub-tile of a stream: rows sub_off, sub_off + sub_mul, ... of the tile
     FastDiv dspp, dwidth, dstripe;                 // n / spp, n / width, n / stripe_rows
 };
 inline void view_set_divisors(DView& v) {
@@ -40,12 +41,14 @@ inline void view_set_divisors(DView& v) {
     v.dstripe = make_fastdiv(v.stripe_rows);
 }
 
-// local pixel index of the tile (row-major over the tile's rows) -> image (row, col)
+// local pixel index of the sub-tile (row-major over ITS rows) -> image (row, col).  Row lr of the sub-tile is row
+// lr * sub_mul + sub_off of the tile; row L of the tile is image row row0 + (L / stripe_rows) * stripe_step + L % stripe_rows.
 __device__ inline void tile_pixel(const DView& v, uint32_t lp, uint32_t& row, uint32_t& col) {
     const uint32_t lr = fdiv(lp, v.dwidth);
     col = lp - lr * v.width;
-    const uint32_t k = fdiv(lr, v.dstripe);
-    row = v.row0 + k * v.stripe_step + (lr - k * v.stripe_rows);
+    const uint32_t L = lr * v.sub_mul + v.sub_off;
+    const uint32_t k = fdiv(L, v.dstripe);
+    row = v.row0 + k * v.stripe_step + (L - k * v.stripe_rows);
 }
 // path index of a batch that starts at local pixel pix0 -> image pixel index (row * width + col) and sample number
 __device__ inline void path_pixel(const DView& v, uint32_t pix0, uint32_t path, uint32_t& row, uint32_t& col, uint32_t& sample) {

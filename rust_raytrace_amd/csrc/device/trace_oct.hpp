@@ -75,7 +75,11 @@ enum : uint32_t { M_IDLE = 0, M_SELECT = 1, M_LEAF = 2, M_SHADE = 3 };
 // (or nothing else is left to do), then they are shaded together and, in the same step, every lane without a ray takes
 // one from the queue.  The arithmetic per path is the per-pass pipeline's (same device functions), so the image is
 // bit-identical; only which lane evaluates it, and when, differs.
-enum : int { W_TRACE = 0, W_PRIMARY = 1, W_BOUNCE = 2 };
+//   W_SLOW     k_path_slow     W_BOUNCE for the slow-path queue (SlowQ, rtmi_device.hip: rays with an exactly-zero direction
+//                              component, ~150 x the work of an ordinary ray): one path per WAVE at a time (lane 0), traced
+//                              and shaded to its end, so that such a ray runs at the speed of a lone lane while the ordinary
+//                              passes go on beside it on their own stream.
+enum : int { W_TRACE = 0, W_PRIMARY = 1, W_BOUNCE = 2, W_SLOW = 3 };
 
 struct OctArgs {
     // W_TRACE
@@ -84,6 +88,8 @@ struct OctArgs {
     DView v; uint64_t seed; uint32_t pix0, npaths;
     float4* bqo; float4* bqd; uint32_t* bqpath;  // bounce queue: filled by W_PRIMARY (ctrl->count[1] entries), drained by W_BOUNCE
     uint16_t* mstack; float4* scol;
+    SlowQ slow;       // W_PRIMARY: where zero-component rays go (cap == 0: nowhere, they are traced in place); W_SLOW: the queue
+    uint32_t slow_k;  // W_SLOW: which consumer launch this is (its range and cursor in the control block)
 };
 
 // Frame of an inner box: node = index of its record; w = visited octants (bits 0-7) | O_DONE | O_HAS;
@@ -126,10 +132,12 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
     // which queue of the control block this launch drains: W_TRACE pass `pass`, W_PRIMARY the implicit queue of all paths
     // of the batch (slot 0), W_BOUNCE the bounce queue (slot 1)
     const int pass = MODE == W_TRACE ? a.pass : (MODE == W_PRIMARY ? 0 : 1);
-    const uint32_t count = MODE == W_PRIMARY ? a.npaths : ctrl->count[pass];
-    if (blockIdx.x == 0 && lane == 0) atomicAdd(&ctrl->rays, (unsigned long long)count);
-    const float4* __restrict__ qo = MODE == W_BOUNCE ? a.bqo : a.qo;
-    const float4* __restrict__ qd = MODE == W_BOUNCE ? a.bqd : a.qd;
+    const uint32_t count = MODE == W_PRIMARY ? a.npaths : (MODE == W_SLOW ? ctrl->shi[a.slow_k] : ctrl->count[pass]);
+    // "Rays": every queued ray of this launch (the slow path counts its rays one by one, below)
+    if (MODE != W_SLOW && blockIdx.x == 0 && lane == 0) atomicAdd(&ctrl->rays, (unsigned long long)count);
+    const float4* __restrict__ qo = MODE == W_BOUNCE ? a.bqo : (MODE == W_SLOW ? a.slow.o : a.qo);
+    const float4* __restrict__ qd = MODE == W_BOUNCE ? a.bqd : (MODE == W_SLOW ? a.slow.d : a.qd);
+    if (MODE == W_SLOW) refill_min = 1;
     uint32_t path = 0;    // W_PRIMARY / W_BOUNCE: the path this lane works for (slot of its sample colour)
     uint32_t bounce = 0;  // bounces the path has behind it = the reference's maxdepth - depth of the ray being traced
     uint32_t ncont = 0;   // W_BOUNCE: rays this lane cast beyond the queued ones (the "Rays" statistic)
@@ -168,7 +176,8 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
         const unsigned long long m_idle = __ballot(mode == M_IDLE);
         // lanes whose ray is finished and waits to be shaded (path kernels only)
         const unsigned long long m_shade = MODE == W_TRACE ? 0ull : __ballot(mode == M_SHADE);
-        const unsigned long long m_x = m_shade | (exhausted ? 0ull : m_idle);  // lanes the exchange step would serve
+        // lanes the exchange step would serve (the slow path keeps one path per wave: only lane 0 ever takes a ray)
+        const unsigned long long m_x = m_shade | (exhausted ? 0ull : (MODE == W_SLOW ? (m_idle & 1ull) : m_idle));
         if (MODE == W_TRACE ? (m_idle == ~0ull && exhausted) : ((m_idle | m_shade) == ~0ull && m_x == 0ull)) break;
         if (m_x != 0ull && (__popcll(m_x) >= refill_min || (m_idle | m_shade) == ~0ull)) {
             // ---- exchange step: finished rays are shaded, lanes without a ray take consecutive queued rays
@@ -187,7 +196,7 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
                                                 a.mstack, a.scol, nr);
                     mode = M_IDLE;
                     if (cont) {
-                        if (MODE == W_BOUNCE) {
+                        if (MODE == W_BOUNCE || MODE == W_SLOW) {
                             no = make_float4(nr.orig.x, nr.orig.y, nr.orig.z, nr.orig.w);
                             nd = make_float4(nr.dir.x, nr.dir.y, nr.dir.z, nr.dir.w);
                             nbounce = bounce + 1u;
@@ -198,6 +207,10 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
                     }
                 }
                 if (MODE == W_PRIMARY) {
+                    if (push && a.slow.cap && has_zero_component(nr.dir.x, nr.dir.y, nr.dir.z) &&
+                        slow_push(a.slow, ctrl, make_float4(nr.orig.x, nr.orig.y, nr.orig.z, nr.orig.w),
+                                  make_float4(nr.dir.x, nr.dir.y, nr.dir.z, nr.dir.w), path, 1u))
+                        push = false;  // its path goes on in k_path_slow
                     const unsigned long long mask = __ballot(push);
                     if (mask) {
                         uint32_t qb = 0;
@@ -212,7 +225,21 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
                     }
                 }
             }
-            const unsigned long long m_want = MODE == W_TRACE ? m_idle : __ballot(mode == M_IDLE);
+            const unsigned long long m_want = MODE == W_TRACE ? m_idle : (MODE == W_SLOW ? (__ballot(mode == M_IDLE) & 1ull) : __ballot(mode == M_IDLE));
+            if (MODE == W_SLOW) {
+                if (!exhausted && m_want != 0ull) {  // lane 0 takes the next entry of this launch's range
+                    uint32_t i = 0;
+                    if (lane == 0) i = ctrl->slo[a.slow_k] + atomicAdd(&ctrl->shead[a.slow_k], 1u);
+                    i = __builtin_amdgcn_readfirstlane(i);
+                    if (i >= count) exhausted = true;
+                    else if (lane == 0) {
+                        no = qo[i]; nd = qd[i];
+                        npath = a.slow.path[i]; nbounce = a.slow.bounce[i];
+                        ncont += nbounce != 0u ? 1u : 0u;  // a diverted bounce ray was not counted by any queue; a primary ray was
+                        start = true;
+                    }
+                }
+            } else
             if (!exhausted && m_want != 0ull) {
                 const uint32_t n = (uint32_t)__popcll(m_want);
                 if (COUNT && lane == 0) { dbg[4]++; dbg[5] += n; }
@@ -241,6 +268,9 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
                             nd = make_float4(pr.dir.x, pr.dir.y, pr.dir.z, pr.dir.w);
                             npath = i; nbounce = 0u;
                             start = true;
+                            // an exactly-zero direction component: ~150 x the work of an ordinary ray and the other 63
+                            // samples of the pixel would wait for it -> its path is traced by k_path_slow
+                            if (a.slow.cap && has_zero_component(nd.x, nd.y, nd.z) && slow_push(a.slow, ctrl, no, nd, i, 0u)) start = false;
                         } else if (MODE == W_BOUNCE) {
                             no = qo[i]; nd = qd[i];
                             npath = a.bqpath[i]; nbounce = 1u;
@@ -257,8 +287,15 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
                     }
                 }
             }
+            if (MODE == W_SLOW && __ballot(start) != 0ull) {
+                // the slow path's one ray per wave (lane 0's) is held by EVERY lane: its leaves are scanned one reference
+                // per lane (the wide LEAF step below)
+                auto bc = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+                const float4 bo = make_float4(bc(no.x), bc(no.y), bc(no.z), bc(no.w)), bd = make_float4(bc(nd.x), bc(nd.y), bc(nd.z), bc(nd.w));
+                r = make_rayk(bo, bd);
+            }
             if (MODE != W_TRACE && start) {  // one place where a path kernel's lane takes a ray: bounce in place, or refill
-                r = make_rayk(no, nd);
+                if (MODE != W_SLOW) r = make_rayk(no, nd);
                 path = npath; bounce = nbounce;
                 fnode = 0; fw = 0; ft = 0.f; lvl = 0;
                 ghave = false; gt = 0.f; gtf = 0;
@@ -387,6 +424,49 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
             }
         } else {
             // ================================================= LEAF step: one block of <= 4 references
+            if (MODE == W_SLOW) {
+                // ---- wide LEAF step of the slow path: the wave holds ONE ray (lane 0 owns its state, every lane has a copy
+                // of the ray), so the leaf is scanned one REFERENCE per lane, 16 blocks per step, and the reference's
+                // sequential fold (get_box_min_time_intersection, raytrace.rs:1012-1050: the first hit is taken, a later
+                // one replaces it iff strictly closer) is replayed over the hits in list order on the scalar unit.
+                const uint32_t lb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lblock);
+                const uint32_t myb = lb0 + ((uint32_t)lane >> 2);
+                const bool inb = myb < sc.noblocks;
+                const uint4 blk = inb ? ld_off32(sc.oblocks, myb << 4) : make_uint4(0u, 0u, 0u, 0u);
+                const uint32_t cpos = (uint32_t)lane & 3u;
+                const uint32_t id = (cpos == 0u ? blk.x : cpos == 1u ? blk.y : cpos == 2u ? blk.z : blk.w) & 0x7FFFFFFFu;
+                const bool term = blk.w == 0u || (blk.w >> 31);            // this block ends the list (a block past the array does too)
+                const unsigned long long tm = __ballot(term);
+                const uint32_t endb = tm ? ((uint32_t)(__ffsll((long long)tm) - 1) >> 2) : 16u;  // first terminating block of the 16
+                const bool valid = (((uint32_t)lane >> 2) <= endb) & (id != 0u);              // a 0 is padding behind the list's end
+                float t = 0.f;
+                uint32_t face = 0u;
+                bool hit = false;
+                if (valid) hit = tri_test<COUNT>(sc, id, r, t, face, cnt);
+                bool have = __builtin_amdgcn_readfirstlane((int)lhave) != 0;
+                float best = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lt)));
+                uint32_t btf = (uint32_t)__builtin_amdgcn_readfirstlane((int)ltf);
+                const uint32_t mytf = id | (face << 30);
+                for (unsigned long long hm = __ballot(hit); hm; hm &= hm - 1ull) {
+                    const int l = __ffsll((long long)hm) - 1;
+                    const float tl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), l));
+                    if (!have || tl < best) { best = tl; btf = (uint32_t)__builtin_amdgcn_readlane((int)mytf, l); }
+                    have = true;
+                }
+                if (lane == 0) {
+                    lhave = have; lt = best; ltf = btf;
+                    if (tm == 0ull) lblock = lb0 + 16u;  // no end among these 16 blocks: the list goes on
+                    else {
+                        if (lhave) {
+                            if (!(fw & O_HAS) || lt < ft) ft = lt;
+                            fw |= O_HAS;
+                            if (!ghave || lt < gt) { gt = lt; gtf = ltf; }
+                            ghave = true;
+                        }
+                        mode = M_SELECT;
+                    }
+                }
+            } else
             if (mode == M_LEAF) {
                 const uint4 blk = ld_off32(sc.oblocks, lblock << 4);
                 const uint32_t ids[4] = {blk.x, blk.y, blk.z, blk.w & 0x7FFFFFFFu};
@@ -462,7 +542,7 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
             if (stepS) dbg[8] += dt; else dbg[9] += dt;
         }
     }
-    if (MODE == W_BOUNCE) {  // "Rays": the queued bounce rays were counted above, the ones cast in place here
+    if (MODE == W_BOUNCE || MODE == W_SLOW) {  // "Rays": the queued bounce rays were counted above, the ones cast in place here
         unsigned long long wsum = 0;
         for (unsigned long long m = __ballot(ncont != 0u); m; m &= m - 1ull)
             wsum += (uint32_t)__builtin_amdgcn_readlane((int)ncont, __ffsll((long long)m) - 1);
@@ -502,6 +582,11 @@ template <bool COUNT, bool FAST>
 __global__ void __launch_bounds__(64, RTMI_PATH_WAVES) k_path_bounce(DScene sc, OctArgs a, DCtrl* __restrict__ ctrl, int refill_min, int xcd_aware) {
     extern __shared__ uint32_t lds[];
     oct_walk<COUNT, FAST, W_BOUNCE>(sc, a, ctrl, lds, refill_min, xcd_aware);
+}
+template <bool COUNT, bool FAST>
+__global__ void __launch_bounds__(64, RTMI_PATH_WAVES) k_path_slow(DScene sc, OctArgs a, DCtrl* __restrict__ ctrl, int refill_min, int xcd_aware) {
+    extern __shared__ uint32_t lds[];
+    oct_walk<COUNT, FAST, W_SLOW>(sc, a, ctrl, lds, refill_min, xcd_aware);
 }
 
 }  // namespace rtmi

@@ -582,6 +582,7 @@ void HipRayCaster::apply_settings() {
     if (tuning_.xcd_aware) t.xcd_aware = tuning_.xcd_aware - 1;
     if (tuning_.kernel) t.kernel = tuning_.kernel;
     if (tuning_.pipeline) t.pipeline = tuning_.pipeline;
+    if (tuning_.slow_path_off) t.slow_path_off = tuning_.slow_path_off;
     set_all(t);
 }
 
@@ -681,7 +682,7 @@ void HipRayCaster::walk_frame_multi(const Viewport& v, const Scene& s, void* dat
         sum.kernel_ms = std::max(sum.kernel_ms, d.kernel_ms);  // the devices run concurrently
         sum.streams = std::max(sum.streams, d.streams);
         sum.render_ms = std::max(sum.render_ms, d.render_ms);
-        sum.primary_ms += d.primary_ms; sum.bounce_ms += d.bounce_ms; sum.pipeline = std::max(sum.pipeline, d.pipeline);
+        sum.primary_ms += d.primary_ms; sum.bounce_ms += d.bounce_ms; sum.pipeline = std::max(sum.pipeline, d.pipeline); sum.slow_paths += d.slow_paths;
         sum.band_copy_ms = std::max(sum.band_copy_ms, d.band_copy_ms);
         sum.deinterleave_ms += d.deinterleave_ms;
     }

@@ -826,6 +826,52 @@ def test_fused_and_per_pass_pipelines_same_image(canonical_pair, circles_pair):
     assert_bits_equal(ref[rd.tile_rows(tile, h)], buf.cpu().numpy(), "striped tile, fused")
 
 
+def test_slow_path_for_zero_direction_components(canonical_pair):
+    """A ray whose unit direction has an exactly-zero component skips that axis' slab in BoundingBox::collides
+    (raytrace.rs:872, :882, :892) and enters every box of the perpendicular plane -- ~150 x the work of an ordinary ray.
+    The default pipeline sets such rays aside (SlowQ) and k_path_slow traces their paths beside the ordinary passes.
+    One-row and one-column images at 1 spp put EVERY primary ray on the camera axis plane (row + 0.5 over a height of 1
+    is exactly the axis), so every path takes the slow route: image bits, "Rays" and all six work counters equal the
+    oracle's and the renders with the slow path switched off / the per-pass pipeline (which has none)."""
+    so, sp = canonical_pair
+    orc, R = _orc(), _R()
+    for (w, h) in ((96, 1), (1, 80), (1, 1)):
+        # image plane 1 x 1: with one row (column) the pixel centre (0 + 0.5) * 1 lies exactly on the camera axis
+        vo = orc.create_viewport(w, h, (1.0, 1.0), [2.0, 0.0, 0.0], orc.unit([0.0, 0.0, 1.0]), 90.0, orc.to_radians(0.0))
+        vp = R.create_viewport((w, h), (1.0, 1.0), [2.0, 0.0, 0.0], R.unit([0.0, 0.0, 1.0]), 90.0, R.to_radians(0.0), 5, 1)
+        assert_bits_equal(vo, vp.vp12, "viewport")
+        ref, cn = so.render(w, h, vo, 5, 1, seed=6, threads=8)
+        o4, d4 = orc.primary_rays(w, h, vo, 1, seed=6)
+        nzero = int(((d4[:, :3] == 0).any(axis=1)).sum())
+        assert nzero == w * h  # the premise of this test
+        for tun, want_slow in (({"pipeline": 3}, True), ({"pipeline": 2}, True), ({"pipeline": 3, "slow_path_off": 1}, False),
+                               ({"pipeline": 1}, False), ({"pipeline": 3, "streams": 2, "subtile_min_paths": 1, "batch_paths": 7}, True)):
+            img = np.zeros((h, w, 4), np.float32)
+            ctx = R.HipRayCaster(seed=6, options=R.OPT_COUNTERS, tuning=tun).walk_rays(vp, sp, img, 1, False)
+            assert_bits_equal(ref, img, f"{w}x{h} {tun}")
+            for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves"):
+                assert ctx.stats[k] == cn[k], (tun, k, ctx.stats[k], cn[k])
+            assert (ctx.stats["slow_paths"] >= w * h) == want_slow, (tun, ctx.stats["slow_paths"])
+            img2 = np.zeros((h, w, 4), np.float32)
+            ctx2 = R.HipRayCaster(seed=6, tuning=tun).walk_rays(vp, sp, img2, 1, False)   # the uncounted kernels
+            assert_bits_equal(ref, img2, f"uncounted {w}x{h} {tun}")
+            assert ctx2.total_rays == cn["rays"]
+    # a frame where only SOME paths may be slow: jittered samples next to the camera axis (`row + v_off` rounds to the axis row
+    # with probability 2^-19 per sample here: usually none -- the frame must be right either way)
+    w, h = 40, 32
+    vo = orc.create_viewport(w, h, (1.0, 1.0), [2.0, 0.0, 0.0], orc.unit([0.0, 0.0, 1.0]), 90.0, orc.to_radians(0.0))
+    vp = R.create_viewport((w, h), (1.0, 1.0), [2.0, 0.0, 0.0], R.unit([0.0, 0.0, 1.0]), 90.0, R.to_radians(0.0), 5, 65)
+    vp.samples_per_pixel = 65
+    o4, d4 = orc.primary_rays(w, h, vo, 65, seed=2)
+    nzero = int(((d4[:, :3] == 0).any(axis=1)).sum())
+    ref, cn = so.render(w, h, vo, 5, 65, seed=2, threads=8)
+    img = np.zeros((h, w, 4), np.float32)
+    ctx = R.HipRayCaster(seed=2).walk_rays(vp, sp, img, 1, False)
+    assert_bits_equal(ref, img, "mixed frame")
+    assert ctx.total_rays == cn["rays"] and ctx.stats["slow_paths"] >= nzero
+    print(f"mixed frame: {nzero} zero-component primary rays of {w * h}, {ctx.stats['slow_paths']} slow paths")
+
+
 def test_pool_kernel_is_bit_exact(canonical_pair):
     """tuning kernel=2 selects k_trace_pool (per-wave ray pool in LDS, free ray-to-lane assignment each step); measured
     slower than the default on MI355X and therefore opt-in, but it stays exact: image bits and all six work

@@ -135,7 +135,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_struct_layouts():
     from rust_raytrace_amd import _ffi
     # the same numbers are static_asserts on the C structs in csrc/device/rtmi_device.hip
-    assert C.sizeof(_ffi.Stats) == 120 and C.sizeof(_ffi.Tile) == 16 and C.sizeof(_ffi.Tuning) == 48  # rtmi_tuning_t: u64 + 10 x u32
+    assert C.sizeof(_ffi.Stats) == 128 and C.sizeof(_ffi.Tile) == 16 and C.sizeof(_ffi.Tuning) == 48  # rtmi_tuning_t: u64 + 10 x u32
 
 
 def test_no_cpu_fallback_without_a_gpu(canonical_pair):
