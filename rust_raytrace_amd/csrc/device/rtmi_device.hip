@@ -1270,7 +1270,7 @@ static void launch_path(rtmi_scene* s, Work& w, hipStream_t st, int which, const
         a.slow_k = (uint32_t)queue;
         (void)hipStreamWaitEvent(w.sstream, w.sev[queue], 0);
         hipLaunchKernelGGL(k_slow_snapshot, dim3(1), dim3(1), 0, w.sstream, w.ctrl.p, (uint32_t)queue, a.slow.cap);
-        const dim3 sgrid((unsigned)(s->num_cu * 2));  // one path per wave at a time; a frame has ~100 such paths
+        const dim3 sgrid((unsigned)std::max(s->num_cu / 2, 1));  // one path per wave at a time; a frame has ~100 such paths, a wave takes one after the other
         if (fast) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_path_slow<COUNT, true>), sgrid, block, s->oct_lds, w.sstream, s->d, a, w.ctrl.p, 1, 0);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_path_slow<COUNT, false>), sgrid, block, s->oct_lds, w.sstream, s->d, a, w.ctrl.p, 1, 0);
         return;

@@ -422,7 +422,11 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
                     }
                 }
             }
-        } else {
+        }
+        // (a second `if`, not an `else`: hipcc's CFG structurizer then has two plain if-regions to handle instead of an
+        // if/else whose join needs copies of every loop-carried register written on either side -- 25 fewer v_mov per iteration,
+        // what round 2 got from an LLVM-internal switch that later miscompiled this loop, csrc/Makefile)
+        if (!stepS) {
             // ================================================= LEAF step: one block of <= 4 references
             if (MODE == W_SLOW) {
                 // ---- wide LEAF step of the slow path: the wave holds ONE ray (lane 0 owns its state, every lane has a copy
