@@ -4,6 +4,7 @@
 
 #include <atomic>
 #include <cfloat>
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -695,8 +696,26 @@ void HipRayCaster::walk_frame_multi(const Viewport& v, const Scene& s, void* dat
 // DefaultRayCaster fans rows out over `threads` CPU threads (raytrace.rs:1175-1196); here the fan-out is over the
 // caster's devices, inside the library.  `threads` is ignored like the reference's CudaRayCaster does.
 void HipRayCaster::walk_rays_internal(const Viewport& v, const Scene& s, Color* data, size_t /*threads*/, ProgressCtx& progress) {
-    if (devices_.size() > 1) walk_frame_multi(v, s, data, nullptr, 0, 0, progress);
-    else walk_rows(v, s, 0, v.height, data, progress);
+    if (devices_.size() > 1) { walk_frame_multi(v, s, data, nullptr, 0, 0, progress); return; }
+    if (!on_progress_) { walk_rows(v, s, 0, v.height, data, progress); return; }
+    // progress while rendering: one render call and one tuple per row band (raytrace.rs:1411, :1429-1435)
+    const size_t bands = std::min(progress_bands_, std::max<size_t>(v.height, 1));
+    rtmi_stats_t sum{};
+    for (size_t b = 0; b < bands; b++) {
+        const size_t r0 = v.height * b / bands, r1 = v.height * (b + 1) / bands;
+        if (r1 == r0) continue;
+        ProgressCtx band;
+        walk_rows(v, s, r0, r1 - r0, data + r0 * v.width, band);
+        progress.total_rays += band.total_rays;
+        progress.kernel_seconds += band.kernel_seconds;
+        sum.rays += band.stats.rays; sum.box_tests += band.stats.box_tests; sum.tri_tests += band.stats.tri_tests;
+        sum.full_tests += band.stats.full_tests; sum.nodes += band.stats.nodes; sum.leaves += band.stats.leaves;
+        sum.kernel_ms += band.stats.kernel_ms; sum.trace_ms += band.stats.trace_ms; sum.trace_launches += band.stats.trace_launches;
+        sum.primary_ms += band.stats.primary_ms; sum.bounce_ms += band.stats.bounce_ms; sum.slow_paths += band.stats.slow_paths;
+        sum.streams = std::max(sum.streams, band.stats.streams); sum.pipeline = band.stats.pipeline;
+        on_progress_(0, r1 - 1, (r1 - r0) * v.width, band.total_rays);
+    }
+    progress.stats = sum;
 }
 
 void quantize_rgb8(const Color* data, size_t npixels, uint8_t* rgb) {

@@ -11,6 +11,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -177,6 +178,13 @@ public:
     void walk_tile_device(const Viewport& v, const Scene& s, const rtmi_tile_t& tile, void* out_device,
                           void* hip_stream, ProgressCtx& progress);
     void set_options(uint32_t opts) { options_ = opts; }
+    // Progress while rendering, as DefaultRayCaster reports it (raytrace.rs:1411, :1429-1435 send one tuple per finished
+    // row / per 10 k rays: (thread, row, pixels done, {"Rays": n}); progress.rs:95-141 draws from them).  With a callback
+    // set, walk_rays_internal renders the frame in `bands` row bands (default 16) and calls it after each one with
+    // (thread = 0, last row of the band, pixels of the band, rays of the band).  Same image; a band is a render call of
+    // its own (its launches do not overlap the next band's), so a frame costs a few per cent more than in one piece.
+    using ProgressFn = std::function<void(size_t thread, size_t row, size_t pixels, uint64_t rays)>;
+    void set_progress(ProgressFn fn, size_t bands = 16) { on_progress_ = std::move(fn); progress_bands_ = bands ? bands : 1; }
     // Launch tuning (rtmi_tuning_t); fields left 0 keep the library defaults.  Never changes a pixel.
     void set_tuning(const rtmi_tuning_t& t) { tuning_ = t; has_tuning_ = true; }
     void clear_tuning() { has_tuning_ = false; }
@@ -196,6 +204,8 @@ private:
     uint32_t options_ = 0;
     rtmi_tuning_t tuning_{}, defaults_{};
     bool has_tuning_ = false;
+    ProgressFn on_progress_;
+    size_t progress_bands_ = 16;
     void apply_settings();
 };
 

@@ -229,10 +229,36 @@ class HipRayCaster:
             _chk(_ffi.lib().rth_caster_set_tuning(s.h, C.byref(t)))
             s._tuned = True
 
-    def walk_rays(self, v, s, data, threads=1, show_progress=False):
+    def walk_rays(self, v, s, data, threads=1, show_progress=False, progress=None, bands=16):
+        """progress: callable(thread, row, pixels, stats) -- what DefaultRayCaster sends over its channel per finished row
+        (raytrace.rs:1411, :1429-1435).  With a callback (or show_progress=True, which prints one line per band like the
+        reference's TUI redraw) the frame is rendered in `bands` row bands, one render call and one tuple each; same image, a
+        few per cent slower than in one piece (a band's launches do not overlap the next band's)."""
         if self.devices and len(self.devices) > 1:
             return self.walk_frame_multi(v, s, data)
-        return self.walk_rows(v, s, 0, v.height, data)
+        if progress is None and not show_progress:
+            return self.walk_rows(v, s, 0, v.height, data)
+        flat = data.reshape(v.height, v.width * 4)
+        total, secs, summed = 0, 0.0, None
+        bands = max(1, min(int(bands), v.height))
+        for b in range(bands):
+            r0, r1 = v.height * b // bands, v.height * (b + 1) // bands
+            if r1 == r0:
+                continue
+            ctx = self.walk_rows(v, s, r0, r1 - r0, flat[r0:r1])
+            total += ctx.total_rays
+            secs += ctx.seconds
+            if summed is None:
+                summed = dict(ctx.stats)
+            else:
+                for k in ("rays", "box_tests", "tri_tests", "full_tests", "nodes", "leaves", "kernel_ms", "trace_ms", "trace_launches",
+                          "primary_ms", "bounce_ms", "slow_paths"):
+                    summed[k] += ctx.stats[k]
+            if progress is not None:
+                progress(0, r1 - 1, (r1 - r0) * v.width, {"Rays": ctx.total_rays})
+            if show_progress:
+                print(f"rows {r0}..{r1 - 1} done: {ctx.stats_line()}", flush=True)
+        return ProgressCtx(total, secs, summed)
 
     def walk_frame_multi(self, v, s, data=None, rgb8=False, stripe_rows=0, out_device_ptr=None):
         """One frame striped over self.devices inside the library.  data: (H, W, 4) f32, or (H, W, 3) u8 with rgb8=True

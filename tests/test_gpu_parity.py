@@ -872,6 +872,26 @@ def test_slow_path_for_zero_direction_components(canonical_pair):
     print(f"mixed frame: {nzero} zero-component primary rays of {w * h}, {ctx.stats['slow_paths']} slow paths")
 
 
+def test_progress_tuples_while_rendering(canonical_pair):
+    """f4 / raytrace.rs:1411, :1429-1435: the reference's caster reports progress per finished row.  With a callback
+    HipRayCaster.walk_rays renders in row bands and reports (thread, last row, pixels, {"Rays"}) after each: the tuples
+    cover every pixel once, their ray counts add up to the frame's, and the image is the one-piece image (== the oracle)."""
+    so, sp = canonical_pair
+    R = _R()
+    w, h, spp = 70, 53, 3
+    vo, vp = _viewports(w, h, 5, spp)
+    ref, cn = so.render(w, h, vo, 5, spp, seed=4, threads=8)
+    for bands in (16, 5, 1, 200):
+        seen = []
+        img = np.zeros((h, w, 4), np.float32)
+        ctx = R.HipRayCaster(seed=4).walk_rays(vp, sp, img, 1, False, progress=lambda t, row, px, st: seen.append((t, row, px, st["Rays"])), bands=bands)
+        assert_bits_equal(ref, img, f"{bands} bands")
+        assert len(seen) == min(bands, h) and seen[-1][1] == h - 1
+        assert [r for _, r, _, _ in seen] == sorted(r for _, r, _, _ in seen)
+        assert sum(px for _, _, px, _ in seen) == w * h and sum(n for _, _, _, n in seen) == cn["rays"] == ctx.total_rays
+        assert ctx.stats["rays"] == cn["rays"]
+
+
 def test_pool_kernel_is_bit_exact(canonical_pair):
     """tuning kernel=2 selects k_trace_pool (per-wave ray pool in LDS, free ray-to-lane assignment each step); measured
     slower than the default on MI355X and therefore opt-in, but it stays exact: image bits and all six work
