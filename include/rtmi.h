@@ -146,6 +146,12 @@ int rtmi_scene_destroy(rtmi_scene_t* scene);
 /* Replace the scene's list of analytic spheres (n may be 0).  At most 4096 spheres (they are not in the tree). */
 int rtmi_scene_set_spheres(rtmi_scene_t* scene, const rtmi_sphere_t* spheres, uint64_t n);
 
+/* Optional: the corners the triangle records were made from (`Triangle.corners`, raytrace.rs:326-337), 9 floats per
+ * triangle, n = ntris (entry 0 = the sentinel's, ignored).  Only RTMI_OPT_BVH uses them: its boxes become the triangles'
+ * own boxes (intersected with the bounding-radius disc's) instead of the disc's alone -- fewer boxes per ray, same hits.
+ * The corners must be the ones the records came from (make_triangle, raytrace.rs:340-383); the exact modes ignore them. */
+int rtmi_scene_set_corners(rtmi_scene_t* scene, const float* corners9, uint64_t n);
+
 /* Option switches (all default 0): */
 enum {
     RTMI_OPT_COUNTERS = 1u << 0, /* fill box/tri/node counters in rtmi_stats_t (slower) */
@@ -158,7 +164,7 @@ enum {
     RTMI_OPT_BVH = 1u << 3       /* "fast mode", NOT the reference's octree traversal: the closest hit over ALL triangles
                                   * with the lowest index winning exact ties, i.e. what the reference computes for a
                                   * build_trivial_bounding_box scene (raytrace.rs:847-856, :1012-1050), found through a
-                                  * SAH BVH the library builds over the triangles' bounding spheres at scene creation (the
+                                  * 4-wide SAH BVH the library builds over the triangles at scene creation (the
                                   * boxes/tri_refs passed in are ignored for tracing).  Bit-equal to the linear-list
                                   * render except for the reference's t = +-inf / NaN "hits" of triangles a ray does not
                                   * come near; differs from the octree render where the octree builder lost a triangle

@@ -113,7 +113,7 @@ def lib():
 
 # every symbol include/rtmi.h and include/rtmi_host.h declare
 RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_scene_set_options",
-                "rtmi_scene_get_tuning", "rtmi_scene_set_tuning", "rtmi_scene_set_spheres", "rtmi_render", "rtmi_render_frame_multi",
+                "rtmi_scene_get_tuning", "rtmi_scene_set_tuning", "rtmi_scene_set_spheres", "rtmi_scene_set_corners", "rtmi_render", "rtmi_render_frame_multi",
                 "rtmi_render_device", "rtmi_render_tile_device", "rtmi_trace", "rtmi_quantize", "rtmi_quantize_device", "rtmi_make_triangles", "rtmi_builder_create", "rtmi_builder_filter", "rtmi_builder_destroy", "rtmi_last_error"]
 RTH_SYMBOLS = ["rth_last_error", "rth_make_color", "rth_unit", "rth_to_radians", "rth_create_transform",
                "rth_create_viewport", "rth_scene_new", "rth_scene_free", "rth_num_tris", "rth_add_triangle", "rth_add_triangles_gpu", "rth_add_obj", "rth_add_obj_mode",

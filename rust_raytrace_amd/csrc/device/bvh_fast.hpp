@@ -12,24 +12,32 @@
 // result can also differ where the octree's builder lost a triangle (false negative of box_contains_polygon) and
 // where two triangles tie exactly; bench.py --bvh reports the differing-pixel count.
 //
-// How: a binary BVH built by the library at scene creation with a binned surface-area heuristic (16 bins on the
-// centroids), leaves of <= 4 triangles.  A triangle can only be hit in its plane inside its bounding radius (the
-// reference's own radius test, raytrace.rs:411-413), so the axis-aligned box of that disc (half-extent
-// r*sqrt(1 - n_k^2), widened) bounds every hit point and the records of rtmi_triangle_t suffice — no corners needed.  Traversal: persistent
-// waves, one lane = one ray, per-lane stack in LDS, the wave alternates INNER steps (both children's slab tests,
-// near child first) and LEAF steps (<= 4 triangles) by majority vote like k_trace_oct; subtrees whose entry distance
-// exceeds the best hit so far are pruned — the lever the exact mode may not use.
+// How: a BVH built by the library at scene creation: binned surface-area heuristic (16 bins on the centroids), leaves of
+// <= 4 triangles, then collapsed to 4-WIDE nodes (one 128-byte record = one cache line per node: the 4 child boxes as
+// six float4 planes + 4 links).  A triangle can only be hit in its plane inside its bounding radius (the reference's own
+// radius test, raytrace.rs:411-413), so the axis-aligned box of that disc (half-extent r*sqrt(1 - n_k^2), widened) bounds
+// every hit point and the records of rtmi_triangle_t suffice; when the caller also hands over the corners
+// (rtmi_scene_set_corners; `Triangle.corners`, raytrace.rs:326-337) the box is that disc box INTERSECTED with the
+// corners' box -- the three half-plane tests (raytrace.rs:415-424) accept points of the triangle only.  Traversal:
+// persistent waves, one lane = one ray, per-lane stack of links in LDS, the wave alternates INNER steps (4 slab tests,
+// the hit children pushed far-to-near so that the nearest is visited next) and LEAF steps (<= 4 triangles: four
+// branch-free plane tests, the edge part once per step for the lanes that have a candidate, as in k_trace_oct) by
+// majority vote; subtrees whose entry distance exceeds the best hit so far are pruned -- the lever the exact mode may
+// not use.
 #pragma once
 
 namespace rtmi {
 
 // ---------------------------------------------------------------- host: binned SAH build
 struct BvhBuild {
-    std::vector<float4> nodes;   // 4 x float4 per inner node: left box, right box, (left link, right link)
+    std::vector<float4> nodes;   // binary build: 4 x float4 per inner node: left box, right box, (left link, right link)
+    std::vector<float4> wide;    // 4-wide form: 8 x float4 per node: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] links[4] pad
     std::vector<uint4> leaves;   // <= 4 triangle indices per leaf, 0-padded
-    uint32_t depth = 0;
+    uint32_t depth = 0;          // of the 4-wide tree (inner levels)
     uint32_t root_link = 0;      // link of the root (a leaf when the scene has <= 4 triangles)
 };
+#define BVH_EMPTY 0xFFFFFFFFu    // link of an unused child slot
+#define BVH_CHUNK 512            // queue entries a wave reserves at a time
 
 struct BBox {
     float lo[3], hi[3];
@@ -42,7 +50,8 @@ struct BBox {
 };
 
 // Builds over triangles 1 .. n-1 (0 is the sentinel).  Returns false when a record is not finite (then no BVH).
-static bool bvh_build(const rtmi_triangle_t* tris, uint64_t ntris, BvhBuild& out) {
+// corners9: optional, 9 floats per triangle (the corners the records were made from), index 0 = the sentinel
+static bool bvh_build(const rtmi_triangle_t* tris, uint64_t ntris, BvhBuild& out, const float* corners9 = nullptr) {
     out = BvhBuild();
     if (ntris < 2) return false;
     const uint32_t n = (uint32_t)(ntris - 1);
@@ -64,6 +73,17 @@ static bool bvh_build(const rtmi_triangle_t* tris, uint64_t ntris, BvhBuild& out
             const float half = r * std::sqrt(s2 > 0.f ? s2 : 0.f) * 1.0001f + eps;
             box[i].lo[k] = t.incenter[k] - half;
             box[i].hi[k] = t.incenter[k] + half;
+            if (corners9) {
+                // an accepted hit point also passes the three half-plane tests (raytrace.rs:415-424): it lies in the triangle
+                // (up to the same rounding margin), i.e. inside the box of the corners
+                const float* c = corners9 + 9 * (size_t)(i + 1);
+                if (!std::isfinite(c[k]) || !std::isfinite(c[3 + k]) || !std::isfinite(c[6 + k])) return false;
+                const float clo = std::min(c[k], std::min(c[3 + k], c[6 + k])) - eps;
+                const float chi = std::max(c[k], std::max(c[3 + k], c[6 + k])) + eps;
+                box[i].lo[k] = std::max(box[i].lo[k], clo);
+                box[i].hi[k] = std::min(box[i].hi[k], chi);
+                if (box[i].lo[k] > box[i].hi[k]) { box[i].lo[k] = t.incenter[k] - half; box[i].hi[k] = t.incenter[k] + half; }  // inconsistent input: keep the disc box
+            }
         }
         idx[i] = i;
     }
@@ -152,23 +172,79 @@ static bool bvh_build(const rtmi_triangle_t* tris, uint64_t ntris, BvhBuild& out
         stack.push_back(Task{mid, tk.hi, tk.depth + 1, me, 1});
         stack.push_back(Task{tk.lo, mid, tk.depth + 1, me, 0});
     }
+    // ---- collapse to 4-wide nodes: a node's children are its binary children, the one with the largest box replaced by
+    //      ITS children until there are four (or only leaves are left)
+    struct Child { BBox b; uint32_t link; };
+    auto child_of = [&](uint32_t node, int side) {
+        const float4* q = &out.nodes[4 * (size_t)node];
+        Child c;
+        if (side == 0) { c.b.lo[0] = q[0].x; c.b.lo[1] = q[0].y; c.b.lo[2] = q[0].z; c.b.hi[0] = q[0].w; c.b.hi[1] = q[1].x; c.b.hi[2] = q[1].y; c.link = __builtin_bit_cast(uint32_t, q[3].x); }
+        else { c.b.lo[0] = q[1].z; c.b.lo[1] = q[1].w; c.b.lo[2] = q[2].x; c.b.hi[0] = q[2].y; c.b.hi[1] = q[2].z; c.b.hi[2] = q[2].w; c.link = __builtin_bit_cast(uint32_t, q[3].y); }
+        return c;
+    };
+    out.depth = 0;
+    if (!(out.root_link >> 31)) {
+        struct WTask { uint32_t bin, wide, depth; };
+        std::vector<WTask> todo;
+        out.wide.assign(8, make_float4(0.f, 0.f, 0.f, 0.f));
+        todo.push_back(WTask{out.root_link, 0u, 1u});
+        out.root_link = 0;  // wide node 0
+        while (!todo.empty()) {
+            const WTask wt = todo.back();
+            todo.pop_back();
+            out.depth = std::max(out.depth, wt.depth);
+            std::vector<Child> ch{child_of(wt.bin, 0), child_of(wt.bin, 1)};
+            while (ch.size() < 4) {
+                int best = -1;
+                float ba = -1.f;
+                for (size_t k = 0; k < ch.size(); k++)
+                    if (!(ch[k].link >> 31) && ch[k].b.area() > ba) { ba = ch[k].b.area(); best = (int)k; }
+                if (best < 0) break;
+                const uint32_t inner = ch[(size_t)best].link;
+                ch[(size_t)best] = child_of(inner, 0);
+                ch.push_back(child_of(inner, 1));
+            }
+            float lo[3][4], hi[3][4];
+            uint32_t link[4];
+            for (int k = 0; k < 4; k++) {
+                for (int a = 0; a < 3; a++) { lo[a][k] = FLT_MAX; hi[a][k] = -FLT_MAX; }
+                link[k] = BVH_EMPTY;
+            }
+            for (size_t k = 0; k < ch.size(); k++) {
+                for (int a = 0; a < 3; a++) { lo[a][k] = ch[k].b.lo[a]; hi[a][k] = ch[k].b.hi[a]; }
+                if (ch[k].link >> 31) link[k] = ch[k].link;
+                else {
+                    link[k] = (uint32_t)(out.wide.size() / 8);
+                    out.wide.resize(out.wide.size() + 8, make_float4(0.f, 0.f, 0.f, 0.f));
+                    todo.push_back(WTask{ch[k].link, link[k], wt.depth + 1});
+                }
+            }
+            float4* w = &out.wide[8 * (size_t)wt.wide];
+            for (int a = 0; a < 3; a++) {
+                w[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+                w[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+            }
+            w[6] = make_float4(__builtin_bit_cast(float, link[0]), __builtin_bit_cast(float, link[1]), __builtin_bit_cast(float, link[2]), __builtin_bit_cast(float, link[3]));
+        }
+    }
     return true;
 }
 
 // ---------------------------------------------------------------- device: traversal
 enum : uint32_t { B_IDLE = 0, B_INNER = 1, B_LEAF = 2 };
 
-// Ray/box slab test on [0, tbest]: entry distance in `tn`.  Conservative (a box is never missed because of rounding:
-// the far plane is widened by 2 ulp, Ize's robust test); NaN operands (0 * inf on a zero direction component whose
-// origin lies on the plane) are ignored by fmaxf/fminf, which keeps the slab open.
+// One child's slab test on [0, tbest]: entry distance in `tn`.  Conservative (a box is never missed because of rounding:
+// the far plane is widened by 2 ulp, Ize's robust test); NaN operands (0 * inf on a zero direction component whose origin
+// lies on the plane) are ignored by v_min/v_max (IEEE minNum/maxNum), which keeps the slab open; an empty slot's inverted
+// box (lo = MAX, hi = -MAX) never passes.
 __device__ inline bool bvh_slab(float lox, float loy, float loz, float hix, float hiy, float hiz, const RayK& r, float tbest, float& tn) {
     const float tx0 = (lox - r.ox) * r.ix, tx1 = (hix - r.ox) * r.ix;
     const float ty0 = (loy - r.oy) * r.iy, ty1 = (hiy - r.oy) * r.iy;
     const float tz0 = (loz - r.oz) * r.iz, tz1 = (hiz - r.oz) * r.iz;
-    const float tmin = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
-    const float tmax = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)) * 1.0000003f;
+    const float tmin = fmaxf(max3f(fminf(tx0, tx1), fminf(ty0, ty1), fminf(tz0, tz1)), 0.f);
+    const float tmax = min3f(fmaxf(tx0, tx1), fmaxf(ty0, ty1), fmaxf(tz0, tz1)) * 1.0000003f;
     tn = tmin;
-    return (tmin <= tmax) & (tmin <= tbest);
+    return (tmin <= tmax) & (tmin <= tbest) & (tmin < INFINITY);
 }
 
 template <bool COUNT>
@@ -191,19 +267,27 @@ __global__ void __launch_bounds__(64, 5) k_trace_bvh(DScene sc, const float4* __
     // closest hit so far (finite time, lowest index on ties)
     float bt = INFINITY;
     uint32_t btf = 0;
+    uint32_t wnext = 0, wend = 0;  // the wave's reserved range of queue entries (wave-uniform)
 
     for (;;) {
         const unsigned long long m_idle = __ballot(mode == B_IDLE);
         if (m_idle == ~0ull && exhausted) break;
         if (!exhausted && (__popcll(m_idle) >= refill_min || m_idle == ~0ull)) {
-            const uint32_t n = (uint32_t)__popcll(m_idle);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&ctrl->head[pass], n);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= count) { exhausted = true; continue; }
-            if (mode == B_IDLE) {
+            // Rays of this mode are short (tens of steps): a wave reserves BVH_CHUNK queue entries with ONE atomic and deals
+            // them out to its idle lanes over several refills -- with one atomic per refill the single queue cursor was the
+            // bottleneck of the bounce passes (8-lane refills: 134 ms per frame, 32-lane refills: 79 ms).
+            if (wnext >= wend) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(&ctrl->head[pass], (uint32_t)BVH_CHUNK);
+                wnext = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                wend = min(wnext + (uint32_t)BVH_CHUNK, count);
+                if (wnext >= count) { exhausted = true; wend = wnext; }
+            }
+            const uint32_t base = wnext;
+            wnext = min(wnext + (uint32_t)__popcll(m_idle), wend);
+            if (!exhausted && mode == B_IDLE) {
                 const uint32_t i = base + (uint32_t)__popcll(m_idle & lt_mask);
-                if (i < count) {
+                if (i < wend) {
                     ridx = i;
                     r = make_rayk(qo[i], qd[i]);
                     cur = root_link; sp = 0;
@@ -211,54 +295,93 @@ __global__ void __launch_bounds__(64, 5) k_trace_bvh(DScene sc, const float4* __
                     mode = (root_link >> 31) ? B_LEAF : B_INNER;
                 }
             }
-            continue;
         }
-        const int nI = __popcll(__ballot(mode == B_INNER));
-        const int nL = __popcll(__ballot(mode == B_LEAF));
+        const unsigned long long mI = __ballot(mode == B_INNER), mL = __ballot(mode == B_LEAF);
+        const int nI = __builtin_popcount((uint32_t)mI) + __builtin_popcount((uint32_t)(mI >> 32));
+        const int nL = __builtin_popcount((uint32_t)mL) + __builtin_popcount((uint32_t)(mL >> 32));
+        const bool stepI = nI >= nL;
         bool pop = false;
-        if (nI >= nL) {
-            // ================================================= INNER step: both children, near one first
+        if (stepI) {
+            // ================================================= INNER step: the node's 4 children
             if (mode == B_INNER) {
-                const float4* q = bnodes + 4 * (size_t)cur;
-                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                if (COUNT) { cnt[0] += 2; cnt[3]++; }
-                float tl, tr;
-                const bool hl = bvh_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, bt, tl);
-                const bool hr = bvh_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, bt, tr);
-                const uint32_t ll = __float_as_uint(q3.x), lr = __float_as_uint(q3.y);
-                if (hl & hr) {
-                    const bool lfirst = tl <= tr;
-                    lds[sp * NT + lane] = lfirst ? lr : ll;
-                    sp++;
-                    cur = lfirst ? ll : lr;
-                } else if (hl | hr) {
-                    cur = hl ? ll : lr;
-                } else pop = true;
-                if (!pop) mode = (cur >> 31) ? B_LEAF : B_INNER;
+                const float4* q = bnodes + 8 * (size_t)cur;
+                const float4 lx = q[0], ly = q[1], lz = q[2], hx = q[3], hy = q[4], hz = q[5], lk = q[6];
+                if (COUNT) { cnt[0] += 4; cnt[3]++; }
+                float t0, t1, t2, t3;
+                uint32_t l[4] = {__float_as_uint(lk.x), __float_as_uint(lk.y), __float_as_uint(lk.z), __float_as_uint(lk.w)};
+                const bool h0 = bvh_slab(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, r, bt, t0) & (l[0] != BVH_EMPTY);
+                const bool h1 = bvh_slab(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, r, bt, t1) & (l[1] != BVH_EMPTY);
+                const bool h2 = bvh_slab(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, r, bt, t2) & (l[2] != BVH_EMPTY);
+                const bool h3 = bvh_slab(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, r, bt, t3) & (l[3] != BVH_EMPTY);
+                // sort the four (distance, link) pairs, missed children last (+inf; a hit's distance is finite): 5 compare-exchanges
+                float d[4] = {h0 ? t0 : INFINITY, h1 ? t1 : INFINITY, h2 ? t2 : INFINITY, h3 ? t3 : INFINITY};
+                auto cx = [&](int a, int b) {
+                    const bool sw = d[b] < d[a];
+                    const float da = sw ? d[b] : d[a], db = sw ? d[a] : d[b];
+                    const uint32_t la = sw ? l[b] : l[a], lb = sw ? l[a] : l[b];
+                    d[a] = da; d[b] = db; l[a] = la; l[b] = lb;
+                };
+                cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
+                const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+                // push the farther ones, farthest first, so that the nearest waiting one is popped first
+                if (nh > 3) { lds[sp * NT + lane] = l[3]; sp++; }
+                if (nh > 2) { lds[sp * NT + lane] = l[2]; sp++; }
+                if (nh > 1) { lds[sp * NT + lane] = l[1]; sp++; }
+                if (nh > 0) { cur = l[0]; mode = (cur >> 31) ? B_LEAF : B_INNER; }
+                else pop = true;
             }
-        } else {
-            // ================================================= LEAF step: <= 4 triangles
+        }
+        if (!stepI) {
+            // ================================================= LEAF step: <= 4 triangles, plane parts branch-free
             if (mode == B_LEAF) {
                 const uint4 blk = bleaves[cur & 0x7FFFFFFFu];
                 const uint32_t ids[4] = {blk.x, blk.y, blk.z, blk.w};
+                float4 p0[4], p1[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { p0[k] = ld_off32(sc.tplane, ids[k] << 5); p1[k] = ld_off32(sc.tplane, (ids[k] << 5) + 16u); }
                 if (COUNT) cnt[4]++;
+                uint32_t ptri = 0u;
+                float pt = 0.f, pix = 0.f, piy = 0.f, piz = 0.f, pden = 0.f;
+                auto resolve = [&]() {  // Triangle::intersects' edge part (raytrace.rs:415-437) for the lane's pending candidate
+                    if (COUNT) cnt[2]++;
+                    const uint32_t eo = ptri << 6;
+                    const float4 e0 = ld_off32(sc.tedge, eo), e1 = ld_off32(sc.tedge, eo + 16u), e2 = ld_off32(sc.tedge, eo + 32u), e3 = ld_off32(sc.tedge, eo + 48u);
+                    const float pz = (r.dw * pt + r.ow) * 0.f;
+                    const float d0 = ((pix * e0.x + piy * e0.y) + piz * e0.z) + pz;
+                    const float d1 = ((pix * e1.x + piy * e1.y) + piz * e1.z) + pz;
+                    const float d2 = ((pix * e2.x + piy * e2.y) + piz * e2.z) + pz;
+                    const bool inside = !(d0 > e0.w) & !(d1 > e1.w) & !(d2 > e2.w);
+                    const bool edge = (d0 > e3.x) | (d1 > e3.y) | (d2 > e3.z);
+                    const uint32_t face = (pden > 0.f ? 1u : 0u) | (edge ? 2u : 0u);
+                    // finite hit times only (see top); strict `<` of the index-order scan: equal times keep the lower index
+                    const bool take = inside & (fabsf(pt) < INFINITY) & ((pt < bt) | ((pt == bt) & (ptri < (btf & 0x3FFFFFFFu))));
+                    bt = take ? pt : bt;
+                    btf = take ? (ptri | (face << 30)) : btf;
+                };
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (ids[k] != 0u) {
-                        float t; uint32_t face;
-                        if (tri_test<COUNT>(sc, ids[k], r, t, face, cnt) && fabsf(t) < INFINITY) {  // finite hit times only (see top)
-                            const uint32_t tf = ids[k] | (face << 30);
-                            // strict `<` of the index-order scan: equal times keep the lower index
-                            if (t < bt || (t == bt && ids[k] < (btf & 0x3FFFFFFFu))) { bt = t; btf = tf; }
-                        }
-                    }
+                    const float ax = p0[k].x - r.ox, ay = p0[k].y - r.oy, az = p0[k].z - r.oz;
+                    const float num = (((0.f + p1[k].x * ax) + p1[k].y * ay) + p1[k].z * az) + r.qn;
+                    const float den = (((0.f + p1[k].x * r.dx) + p1[k].y * r.dy) + p1[k].z * r.dz) + r.qd;
+                    const float t = num / den;
+                    const float px = r.dx * t + r.ox, py = r.dy * t + r.oy, pz_ = r.dz * t + r.oz, pw = r.dw * t + r.ow;
+                    const float ix = px - p0[k].x, iy = py - p0[k].y, iz = pz_ - p0[k].z;
+                    const float l2 = ((ix * ix + iy * iy) + iz * iz) + pw * pw;
+                    const bool real = ids[k] != 0u;
+                    if (COUNT) cnt[1] += real ? 1u : 0u;
+                    const bool c = real & !(t < 0.f) & !(l2 > p0[k].w);
+                    if (c & (ptri != 0u)) resolve();  // second candidate of this lane in one leaf: rare
+                    ptri = c ? ids[k] : ptri;
+                    pt = c ? t : pt;
+                    pix = c ? ix : pix; piy = c ? iy : piy; piz = c ? iz : piz;
+                    pden = c ? den : pden;
                 }
+                if (ptri != 0u) resolve();
                 pop = true;
             }
         }
         if (pop) {
-            // next waiting subtree that can still hold a closer (or equal, lower-index) hit; its entry distance is not
-            // kept on the stack: it is re-tested when the subtree is visited (INNER step) or costs one leaf
+            // next waiting subtree; its entry distance is not kept on the stack: it is re-tested when the subtree is visited
             if (sp > 0) {
                 sp--;
                 cur = lds[sp * NT + lane];

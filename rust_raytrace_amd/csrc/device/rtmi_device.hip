@@ -749,6 +749,7 @@ struct rtmi_scene {
     DevBuf<uint32_t> refs;
     DevBuf<float4> tplane, tedge, mats, spheres;
     std::vector<float4> hmats;  // the triangles' surface table (host copy): sphere surfaces are appended to it
+    std::vector<rtmi_triangle_t> htris;  // the records (host copy): the fast-mode BVH is rebuilt from them when corners arrive
     DevBuf<uint4> fnodes, oblocks;
     DevBuf<uint32_t> wlinks;
     // RTMI_OPT_BVH: SAH BVH over the triangles' bounding spheres (bvh_fast.hpp)
@@ -789,6 +790,31 @@ struct rtmi_scene {
     bool verbose = false;
     unsigned long long vprev[RTMI_MAX_STREAMS][13] = {};  // verbose per-pass deltas (per handle: no shared statics)
 };
+
+// (Re)build the fast-mode BVH (bvh_fast.hpp) from the scene's triangle records and, when given, their corners.
+static int upload_bvh(rtmi_scene* s, const float* corners9) {
+    s->bvh_ok = false;
+    BvhBuild bb;
+    if (s->htris.size() >= (1u << 26) || !bvh_build(s->htris.data(), s->htris.size(), bb, corners9)) return RTMI_OK;  // no BVH: RTMI_OPT_BVH is then ignored
+    if (bb.wide.empty()) bb.wide.resize(8, make_float4(0.f, 0.f, 0.f, 0.f));
+    auto up = [&](auto& buf, const auto& host) -> hipError_t {
+        hipError_t e = buf.ensure(std::max<size_t>(host.size(), 1));
+        if (e != hipSuccess || host.empty()) return e;
+        return hipMemcpy(buf.p, host.data(), host.size() * sizeof(host[0]), hipMemcpyHostToDevice);
+    };
+    hipError_t be = up(s->bnodes, bb.wide);
+    if (be == hipSuccess) be = up(s->bleaves, bb.leaves);
+    if (be != hipSuccess) return fail(hip_code(be), std::string("scene upload (BVH): ") + hipGetErrorString(be));
+    s->bvh_root = bb.root_link;
+    s->bvh_lds = (size_t)(3 * bb.depth + 2) * 64 * 4;  // an INNER step leaves at most 3 links waiting per level
+    int nb = 0;
+    if (s->bvh_lds <= 64 * 1024 &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_bvh<false>, 64, s->bvh_lds) == hipSuccess && nb > 0) {
+        s->bvh_blocks_per_cu = nb;
+        s->bvh_ok = true;
+    } else (void)hipGetLastError();
+    return RTMI_OK;
+}
 
 static size_t env_size(const char* name, size_t dflt) {
     const char* s = getenv(name);
@@ -1053,22 +1079,10 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
             }
         }
     }
-    {   // fast-mode BVH (cheap: binned SAH over bounding spheres); absent when a record is not finite
-        BvhBuild bb;
-        if (bvh_build(tris, ntris, bb)) {
-            if (bb.nodes.empty()) bb.nodes.resize(4, make_float4(0.f, 0.f, 0.f, 0.f));
-            hipError_t be = up(s->bnodes, bb.nodes);
-            if (be == hipSuccess) be = up(s->bleaves, bb.leaves);
-            if (be != hipSuccess) return fail(hip_code(be), std::string("scene upload (BVH): ") + hipGetErrorString(be));
-            s->bvh_root = bb.root_link;
-            s->bvh_lds = (size_t)(bb.depth + 2) * 64 * 4;
-            int nb = 0;
-            if (s->bvh_lds <= 64 * 1024 &&
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_bvh<false>, 64, s->bvh_lds) == hipSuccess && nb > 0) {
-                s->bvh_blocks_per_cu = nb;
-                s->bvh_ok = true;
-            }
-        }
+    s->htris.assign(tris, tris + ntris);  // rtmi_scene_set_corners rebuilds the fast-mode BVH from them
+    {   // fast-mode BVH (cheap: binned SAH over the triangles' disc boxes); absent when a record is not finite
+        const int rc = upload_bvh(s, nullptr);
+        if (rc != RTMI_OK) return rc;
     }
     own.s = nullptr;
     *out = s;
@@ -1130,6 +1144,17 @@ int rtmi_scene_set_spheres(rtmi_scene_t* s, const rtmi_sphere_t* sp, uint64_t n)
     s->d.spheres = s->spheres.p;
     s->d.nspheres = (uint32_t)n;
     return RTMI_OK;
+    RTMI_GUARD_END
+}
+
+int rtmi_scene_set_corners(rtmi_scene_t* s, const float* corners9, uint64_t n) {
+    if (!s) return fail(RTMI_ERR_INVALID, "scene is NULL");
+    if (!corners9) return fail(RTMI_ERR_INVALID, "corners is NULL");
+    if (n != s->htris.size()) return fail(RTMI_ERR_INVALID, "one corner triple per triangle of the scene (the sentinel included)");
+    RTMI_GUARD_BEGIN
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());  // no render of this scene is in flight (one call at a time per handle)
+    return upload_bvh(s, corners9);
     RTMI_GUARD_END
 }
 

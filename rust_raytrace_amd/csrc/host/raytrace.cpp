@@ -612,6 +612,20 @@ rtmi_scene_t* HipRayCaster::resident(const Scene& s) {
         }
         extra_.push_back(e);
     }
+    {   // the corners (`Triangle.corners`): tighter boxes for the opt-in fast mode; the exact modes do not use them
+        std::vector<float> corners(9 * s.tris.size());
+        for (size_t i = 0; i < s.tris.size(); i++)
+            for (int k = 0; k < 3; k++)
+                for (int a = 0; a < 3; a++) corners[9 * i + 3 * k + a] = s.tris[i].corners[k].v[a];
+        std::vector<rtmi_scene_t*> all{handle_};
+        all.insert(all.end(), extra_.begin(), extra_.end());
+        for (rtmi_scene_t* hh : all)
+            if (rtmi_scene_set_corners(hh, corners.data(), s.tris.size()) != RTMI_OK) {
+                const std::string msg = std::string("rtmi_scene_set_corners: ") + rtmi_last_error();
+                invalidate();
+                throw std::runtime_error(msg);
+            }
+    }
     if (!s.spheres.empty()) {
         std::vector<rtmi_sphere_t> sp(s.spheres.size());
         for (size_t i = 0; i < sp.size(); i++) {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development aid: config 3 frame through the fused path kernels for a list of tunings (python dicts, one per argv)."""
+"""Development aid: config 3 frame for a list of tunings (python dicts, one per argv; the key "options" = rtmi option bits)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,7 +12,8 @@ st = torch.cuda.current_stream().cuda_stream
 buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
 for arg in sys.argv[1:]:
     tun = eval(arg)
-    c = R.HipRayCaster(seed=1, tuning=tun)
+    opts = tun.pop("options", 0)  # e.g. R.OPT_BVH = 8
+    c = R.HipRayCaster(seed=1, options=opts, tuning=tun)
     c.walk_tile_device(vp, scene, (0, H, H, 0), buf.data_ptr(), st)
     best = None
     for _ in range(3):
@@ -23,4 +24,4 @@ for arg in sys.argv[1:]:
             best = (dt, ctx)
     dt, ctx = best
     s = ctx.stats
-    print(f"{str(tun):70s} wall {dt:7.1f} ms primary {s['primary_ms']:7.1f} bounce {s['bounce_ms']:7.1f} {ctx.total_rays / dt / 1e3:7.1f} Mrays/s", flush=True)
+    print(f"{str(tun):70s} opt {opts} wall {dt:7.1f} ms primary {s['primary_ms']:7.1f} bounce {s['bounce_ms']:7.1f} {ctx.total_rays / dt / 1e3:7.1f} Mrays/s", flush=True)
