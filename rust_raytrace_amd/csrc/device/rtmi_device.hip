@@ -726,7 +726,7 @@ struct Work {
     DevBuf<uint32_t> sqpath, sqbounce;
     hipStream_t sstream = nullptr;
     std::vector<hipEvent_t> sev;
-    hipEvent_t sdone = nullptr;
+    hipEvent_t sdone = nullptr, sgo = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> pass_ev;  // start/stop of the trace kernel of every pass
     void release() {
@@ -739,6 +739,7 @@ struct Work {
         for (hipEvent_t e : sev) (void)hipEventDestroy(e);
         sev.clear();
         if (sdone) { (void)hipEventDestroy(sdone); sdone = nullptr; }
+        if (sgo) { (void)hipEventDestroy(sgo); sgo = nullptr; }
         if (sstream) { (void)hipStreamDestroy(sstream); sstream = nullptr; }
         cap = 0; cap_depth = 0; full = false;
     }
@@ -1206,6 +1207,7 @@ static int ensure_workspace(Work& w, size_t cap, uint32_t maxdepth, bool fused) 
         HIPCHK(hipStreamCreateWithPriority(&w.sstream, hipStreamNonBlocking, hi));
     }
     if (!w.sdone) HIPCHK(hipEventCreateWithFlags(&w.sdone, hipEventDisableTiming));
+    if (!w.sgo) HIPCHK(hipEventCreateWithFlags(&w.sgo, hipEventDisableTiming));
     while (w.sev.size() < (size_t)std::max<uint32_t>(maxdepth, 2u)) {
         hipEvent_t e;
         HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1298,6 +1300,12 @@ static void launch_path(rtmi_scene* s, Work& w, hipStream_t st, int which, const
         a.slow_k = (uint32_t)queue;
         (void)hipStreamWaitEvent(w.sstream, w.sev[queue], 0);
         hipLaunchKernelGGL(k_slow_snapshot, dim3(1), dim3(1), 0, w.sstream, w.ctrl.p, (uint32_t)queue, a.slow.cap);
+        // The ordinary stream goes on only after the snapshot: its next persistent launch and the slow-path launch then become
+        // ready together and the high-priority one gets its few wave slots first.  (Without this the next launch, already
+        // queued in order, took every slot while the side stream was still resolving the event, and the slow paths started
+        // a whole pass late.)
+        (void)hipEventRecord(w.sgo, w.sstream);
+        (void)hipStreamWaitEvent(st, w.sgo, 0);
         const dim3 sgrid((unsigned)std::max(s->num_cu / 2, 1));  // one path per wave at a time; a frame has ~100 such paths, a wave takes one after the other
         if (fast) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_path_slow<COUNT, true>), sgrid, block, s->oct_lds, w.sstream, s->d, a, w.ctrl.p, 1, 0);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_path_slow<COUNT, false>), sgrid, block, s->oct_lds, w.sstream, s->d, a, w.ctrl.p, 1, 0);
