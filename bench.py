@@ -182,8 +182,12 @@ def main():
         ev[2].record(stream)
         return ctx, frame
 
+    first_gather_ms = None  # the first gather of the process: communicator set-up (RCCL ring/tree construction) included
     for _ in range(args.warmup):
         step()
+        if first_gather_ms is None:
+            ev[2].synchronize()
+            first_gather_ms = ev[1].elapsed_time(ev[2])
     barrier()
     t0 = time.perf_counter()
     rays = 0
@@ -202,7 +206,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    mine = torch.tensor([float(rays), dt, render_ms / args.steps, gather_ms / args.steps], dtype=torch.float64, device=dev)
+    mine = torch.tensor([float(rays), dt, render_ms / args.steps, gather_ms / args.steps, t_build, t_upload,
+                         first_gather_ms if first_gather_ms is not None else -1.0], dtype=torch.float64, device=dev)
     per_rank = [mine]
     if world > 1:
         per_rank = [torch.zeros_like(mine) for _ in range(world)]
@@ -212,6 +217,9 @@ def main():
     n_ranks_seen = len(per_rank)
     rank_render_ms = [round(float(p[2]), 3) for p in per_rank]
     rank_gather_ms = [round(float(p[3]), 3) for p in per_rank]
+    rank_build_s = [round(float(p[4]), 3) for p in per_rank]
+    rank_upload_s = [round(float(p[5]), 3) for p in per_rank]
+    rank_first_gather_ms = [round(float(p[6]), 3) if float(p[6]) >= 0 else None for p in per_rank]
 
     roofline = None
     cpu_baseline = None
@@ -274,7 +282,9 @@ def main():
                        "tiling": f"{world} x interleaved {args.stripe_rows}-row stripes + one gather of " + ("3 B/pixel (u8 RGB, quantised on each GPU)" if args.u8 else "16 B/pixel (f32 x 4)"),
                        "rays_per_frame": int(rays / args.steps)},
             "ranks": {"n_ranks_seen": n_ranks_seen, "backend": args.backend if world > 1 else None,
-                      "render_ms_per_rank": rank_render_ms, "gather_ms_per_rank": rank_gather_ms},
+                      "render_ms_per_rank": rank_render_ms, "gather_ms_per_rank": rank_gather_ms,
+                      "first_gather_ms_per_rank": rank_first_gather_ms,  # warm-up step 1: communicator set-up included (null without warm-up)
+                      "octree_build_s_per_rank": rank_build_s, "scene_upload_s_per_rank": rank_upload_s},
             "value_incl_frame_d2h": incl_d2h, "opt_in_mode_vs_exact": fast_vs_exact,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "setup": {"octree_build_s": round(t_build, 2), "scene_upload_s": round(t_upload, 3)},
