@@ -1770,6 +1770,10 @@ int rtmi_trace(rtmi_scene_t* s, uint64_t n, const float* orig4, const float* dir
     RTMI_GUARD_END
 }
 
+// Test hook (not in rtmi.h): n / d as the kernels compute it for launch-constant divisors (FastDiv, shade.hpp), evaluated on
+// the host with the same inline functions; needs no device.
+uint32_t rtmi_debug_fastdiv(uint32_t n, uint32_t d) { return fdiv(n, make_fastdiv(d)); }
+
 // Test hook (not in rtmi.h): the ABI status and message a HIP runtime failure `hip_error` is reported as.
 int rtmi_debug_status_of(int hip_error) {
     HIPCHK((hipError_t)hip_error);

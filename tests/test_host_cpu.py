@@ -200,3 +200,24 @@ def test_obj_loader_default_is_reference_and_robust_is_opt_in(tmp_path):
     # the teapot has only triangles: both modes give the same records
     a, b = load(TEAPOT_TRI, False), load(TEAPOT_TRI, True)
     assert_bits_equal(a, b, "teapot, both modes")
+
+
+def test_launch_constant_division_is_exact():
+    """The kernels map a path index to (pixel, sample) and a pixel to (row, column) by dividing by the samples per pixel, the
+    image width and the stripe height with a multiply-high (FastDiv, csrc/device/shade.hpp: Granlund & Montgomery 1994,
+    figure 4.1).  The same inline functions evaluated on the host must equal integer division for every divisor shape:
+    1, powers of two, odd, 2^k +- 1, large, and dividends up to 2^32 - 1."""
+    from rust_raytrace_amd import _ffi
+    lib = _ffi.lib()
+    lib.rtmi_debug_fastdiv.restype = C.c_uint32
+    lib.rtmi_debug_fastdiv.argtypes = [C.c_uint32, C.c_uint32]
+    rng = np.random.default_rng(3)
+    divisors = [1, 2, 3, 4, 5, 6, 7, 9, 10, 16, 17, 31, 32, 33, 63, 64, 65, 127, 130, 255, 256, 257, 1000, 1023, 1024, 1025, 2047, 2048,
+                4095, 4096, 65535, 65536, 65537, 10 ** 6, 2 ** 24 - 1, 2 ** 24 + 1, 2 ** 31 - 1, 2 ** 31, 2 ** 31 + 1, 2 ** 32 - 1]
+    divisors += [int(x) for x in rng.integers(1, 2 ** 32, 60)]
+    for d in divisors:
+        ns = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1, 2 ** 32 - d, (2 ** 32 - 1) // d * d, (2 ** 32 - 1) // d * d - 1]
+        ns += [int(x) for x in rng.integers(0, 2 ** 32, 200)]
+        for n in ns:
+            if 0 <= n < 2 ** 32:
+                assert lib.rtmi_debug_fastdiv(n, d) == n // d, (n, d)
