@@ -179,7 +179,8 @@ int rtmi_scene_set_options(rtmi_scene_t* scene, uint32_t options);
 typedef struct rtmi_tuning {
     uint64_t batch_paths;       /* paths (pixel samples) per batch of the wavefront pipeline, all streams together; default 256 Mi.
                                    A tile up to 1/8 larger is still rendered as one batch.                    */
-    uint32_t streams;           /* 1..4 internal HIP streams (interleaved sub-tiles of a tile); default 3        */
+    uint32_t streams;           /* 1..4 internal HIP streams (interleaved sub-tiles of a tile); 0 (default) = automatic:
+                                   one stream for tiles of 2^26 paths and more, three below                    */
     uint32_t subtile_min_paths; /* tiles with fewer paths are not split over streams; default 32768           */
     uint32_t oct_waves_per_cu;  /* persistent waves per CU and launch of the octree kernel; 0 = automatic: what
                                    fits with one stream, at most 16 when several streams share the CUs       */
@@ -213,9 +214,9 @@ int rtmi_scene_set_tuning(rtmi_scene_t* scene, const rtmi_tuning_t* in);
  * rtmi_render writes host memory; rtmi_render_device writes device memory on
  * `hip_stream` (a hipStream_t, or NULL for the default stream) and returns
  * after the work is enqueued and the counters are read back. */
-/* Internally a tile is rendered as rtmi_tuning_t.streams (default 3) interleaved sub-tiles, each on its own HIP stream
- * of the library (the tail of one sub-tile's persistent kernels overlaps the bulk of another's); they start after the
- * work already queued on `hip_stream` and that stream is made to wait for them. */
+/* Internally a tile is rendered as rtmi_tuning_t.streams sub-tiles (rows dealt out one by one), each on its own HIP stream
+ * of the library (the tail of one sub-tile's persistent kernels overlaps the bulk of another's; large tiles use one);
+ * they start after the work already queued on `hip_stream` and that stream is made to wait for them. */
 int rtmi_render(rtmi_scene_t* scene, const rtmi_viewport_t* vp, uint64_t seed,
                 uint32_t row0, uint32_t nrows, float* out_host, rtmi_stats_t* stats);
 int rtmi_render_device(rtmi_scene_t* scene, const rtmi_viewport_t* vp, uint64_t seed,

@@ -512,11 +512,12 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed
                                                float4* __restrict__ qd_n, uint32_t* __restrict__ qpath_n,
                                                uint16_t* __restrict__ mstack, float4* __restrict__ scol,
                                                DCtrl* __restrict__ ctrl, SlowQ slow) {
+    __shared__ uint32_t s_cnt[4], s_base;
     const uint32_t count = ctrl->count[pass];
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t lane = threadIdx.x & 63u;
-    // round the loop bound up so that whole waves stay converged for the ballot
-    const uint32_t bound = (count + 63u) & ~63u;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    // round the loop bound up so that whole BLOCKS stay converged for the ballot and the block-wide queue reservation
+    const uint32_t bound = (count + 255u) & ~255u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < bound; i += stride) {
         bool push = false;
         RayV nr;
@@ -540,12 +541,20 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed
                           path, (uint32_t)pass + 1u))
                 push = false;
         }
-        // compact surviving rays into the next queue: ballot + prefix sum, one atomic per wave
+        // compact surviving rays into the next queue: ballot + prefix sum per wave, ONE atomic per block of four waves.  (One
+        // per wave made the queue counter the kernel's bottleneck: 1.7 M same-address atomics per frame at ~4.8 ns each were
+        // half of its 16.7 ms.)
         const unsigned long long mask = __ballot(push);
-        if (mask) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&ctrl->count[pass + 1], (uint32_t)__popcll(mask));
-            base = __builtin_amdgcn_readfirstlane(base);
+        if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            s_base = total ? atomicAdd(&ctrl->count[pass + 1], total) : 0u;
+        }
+        __syncthreads();
+        {
+            uint32_t base = s_base;
+            for (uint32_t k = 0; k < wv; k++) base += s_cnt[k];
             if (push) {
                 const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
                 qo_n[slot] = make_float4(nr.orig.x, nr.orig.y, nr.orig.z, nr.orig.w);
@@ -553,6 +562,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed
                 qpath_n[slot] = path;
             }
         }
+        __syncthreads();  // s_cnt / s_base are rewritten by the next iteration
     }
 }
 
@@ -1014,7 +1024,7 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     rtmi_scene* s = own.s;
     s->device = device;
     s->tune.batch_paths = env_size("RTMI_BATCH_PATHS", (size_t)256 << 20);
-    s->tune.streams = (uint32_t)std::min<size_t>(env_size("RTMI_STREAMS", 3), RTMI_MAX_STREAMS);
+    s->tune.streams = (uint32_t)std::min<size_t>(env_size("RTMI_STREAMS", 0), RTMI_MAX_STREAMS);
     s->tune.subtile_min_paths = (uint32_t)std::min<size_t>(env_size("RTMI_SUBTILE_MIN_PATHS", 32768), 0xFFFFFFFFu);
     s->tune.oct_waves_per_cu = (uint32_t)std::min<size_t>(env_size("RTMI_OCT_WAVES_PER_CU", 0), 32);
     s->tune.refill_min0 = (uint32_t)std::min<size_t>(env_size("RTMI_REFILL_MIN0", 64), 64);
@@ -1170,7 +1180,7 @@ int rtmi_scene_get_tuning(rtmi_scene_t* s, rtmi_tuning_t* out) {
 
 int rtmi_scene_set_tuning(rtmi_scene_t* s, const rtmi_tuning_t* in) {
     if (!s || !in) return fail(RTMI_ERR_INVALID, "NULL argument");
-    if (in->batch_paths == 0 || in->streams < 1 || in->streams > RTMI_MAX_STREAMS || in->oct_waves_per_cu > 32 || in->refill_min0 < 1 ||
+    if (in->batch_paths == 0 || in->streams > RTMI_MAX_STREAMS || in->oct_waves_per_cu > 32 || in->refill_min0 < 1 ||
         in->refill_min0 > 64 || in->refill_min < 1 || in->refill_min > 64 || in->xcd_aware > 2 || in->kernel > 2 || in->pipeline > 3 || in->slow_path_off > 1)
         return fail(RTMI_ERR_INVALID, "tuning value out of range");
     s->tune = *in;
@@ -1386,7 +1396,20 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     //      shares whatever the tile's own striping is.  (Round 2 dealt out whole stripes: with the 16-row stripes of an
     //      8-rank tiling a stream's stripes repeat every 384 image rows, the teapot covers two such periods and the slowest
     //      stream of a rank carried up to 12 % more rays than the others.)
-    uint32_t nsub = std::min<uint32_t>(std::max<uint32_t>(s->tune.streams, 1u), (uint32_t)RTMI_MAX_STREAMS);
+    // path kernels (pipelines 2 and 3): exact-octree scenes traced by k_trace_oct's walk; everything else (linear list, generic
+    // tree, BVH mode, ray-pool kernel, analytic spheres) runs one launch per bounce pass
+    const bool pool_kernel = s->pool_P != 0 && s->tune.kernel != 1u && (s->tune.kernel == 2u || RTMI_DEFAULT_POOL);
+    // 0 = automatic = 3: k_path_primary, then one launch per bounce pass (measured fastest on MI355X at every tile size,
+    // DESIGN.md 4.1c)
+    const bool hybrid_req = s->tune.pipeline == 3u || s->tune.pipeline == 0u;
+    const bool fused = s->tune.pipeline != 1u && s->octree && !s->root_is_leaf && !(s->options & (RTMI_OPT_GENERIC | RTMI_OPT_BVH)) &&
+                       !pool_kernel && s->d.nspheres == 0;
+    // streams = 0 (automatic): one stream for path-kernel tiles of 2^26 paths and more, three otherwise (the per-pass
+    // pipelines -- BVH mode: 29.6 ms on three streams, 35.2 on one -- have elementwise kernels to hide).  Since k_shade stopped being
+    // atomic-bound (round 3) there is little left for a second stream to hide: the full config-3 frame takes 366.9 ms on one
+    // stream and 371.8 on three (the sub-tiles' persistent launches compete for the same wave slots); a 1/8 tile 52.1 vs 51.6.
+    const uint32_t auto_streams = (fused && npix * spp >= (1ull << 26)) ? 1u : 3u;
+    uint32_t nsub = std::min<uint32_t>(s->tune.streams ? s->tune.streams : auto_streams, (uint32_t)RTMI_MAX_STREAMS);
     nsub = std::min<uint32_t>(nsub, nrows);
     if (npix * spp < s->tune.subtile_min_paths) nsub = 1;
     s->active_streams = nsub;
@@ -1418,14 +1441,6 @@ int rtmi_render_tile_device(rtmi_scene_t* s, const rtmi_viewport_t* vp, uint64_t
     }
     pix_per_batch = std::min<uint64_t>(pix_per_batch, max_sub_npix);
     if (pix_per_batch * spp >= (1ull << 31)) return fail(RTMI_ERR_UNSUPPORTED, "batch above 2^31 paths");
-    // fused path kernels (pipeline 2, the default): exact-octree scenes traced by k_trace_oct's walk; everything else
-    // (linear list, generic tree, BVH mode, ray-pool kernel, analytic spheres) runs one launch per bounce pass
-    const bool pool_kernel = s->pool_P != 0 && s->tune.kernel != 1u && (s->tune.kernel == 2u || RTMI_DEFAULT_POOL);
-    // 0 = automatic = 3: fused primary kernel, then one launch per bounce pass on the sub-tiles' streams (measured fastest
-    // on MI355X at every tile size)
-    const bool hybrid_req = s->tune.pipeline == 3u || s->tune.pipeline == 0u;
-    const bool fused = s->tune.pipeline != 1u && s->octree && !s->root_is_leaf && !(s->options & (RTMI_OPT_GENERIC | RTMI_OPT_BVH)) &&
-                       !pool_kernel && s->d.nspheres == 0;
     for (uint32_t t = 0; t < nsub; t++) {
         int rc = ensure_workspace(s->w[t], (size_t)(std::min<uint64_t>(pix_per_batch, sub[t].npix) * spp), maxdepth, fused && !hybrid_req);
         if (rc != RTMI_OK) return rc;
