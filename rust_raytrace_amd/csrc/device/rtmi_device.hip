@@ -557,9 +557,9 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, DView v, uint64_t seed
             for (uint32_t k = 0; k < wv; k++) base += s_cnt[k];
             if (push) {
                 const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                qo_n[slot] = make_float4(nr.orig.x, nr.orig.y, nr.orig.z, nr.orig.w);
-                qd_n[slot] = make_float4(nr.dir.x, nr.dir.y, nr.dir.z, nr.dir.w);
-                qpath_n[slot] = path;
+                store_stream(&qo_n[slot], make_float4(nr.orig.x, nr.orig.y, nr.orig.z, nr.orig.w));
+                store_stream(&qd_n[slot], make_float4(nr.dir.x, nr.dir.y, nr.dir.z, nr.dir.w));
+                store_stream(&qpath_n[slot], path);
             }
         }
         __syncthreads();  // s_cnt / s_base are rewritten by the next iteration

@@ -149,7 +149,7 @@ __device__ inline bool shade_hit(const DScene& sc, uint32_t maxdepth, uint64_t s
         const float4 mm = sc.mats[2 * mj];
         c = mix_color(mk(mm.x, mm.y, mm.z), c, mm.w);
     }
-    scol[path] = make_float4(c.x, c.y, c.z, c.w);
+    store_stream(&scol[path], make_float4(c.x, c.y, c.z, c.w));
     return false;
 }
 

@@ -218,9 +218,9 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
                         qb = __builtin_amdgcn_readfirstlane(qb);
                         if (push) {
                             const uint32_t slot = qb + (uint32_t)__popcll(mask & lt_mask);
-                            a.bqo[slot] = make_float4(nr.orig.x, nr.orig.y, nr.orig.z, nr.orig.w);
-                            a.bqd[slot] = make_float4(nr.dir.x, nr.dir.y, nr.dir.z, nr.dir.w);
-                            a.bqpath[slot] = path;
+                            store_stream(&a.bqo[slot], make_float4(nr.orig.x, nr.orig.y, nr.orig.z, nr.orig.w));
+                            store_stream(&a.bqd[slot], make_float4(nr.dir.x, nr.dir.y, nr.dir.z, nr.dir.w));
+                            store_stream(&a.bqpath[slot], path);
                         }
                     }
                 }

@@ -51,4 +51,18 @@ __host__ __device__ inline void rng_block(uint64_t seed, uint32_t pixel, uint32_
     philox4x32_10(blk, sample, pixel, 0x52544d49u, (uint32_t)seed, (uint32_t)(seed >> 32), out);
 }
 
+// Streaming stores: sample colours and queue entries are written once and read once by a LATER launch; written with the
+// non-temporal hint they do not displace the scene's boxes and triangles from L2 (4 MB per XCD) while a trace kernel runs.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline void store_stream(float4* p, float4 v) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<v4f*>(p));
+}
+__device__ inline void store_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+#else  // host pass of the same translation unit: never executed
+__device__ inline void store_stream(float4* p, float4 v) { *p = v; }
+__device__ inline void store_stream(uint32_t* p, uint32_t v) { *p = v; }
+#endif
+
 }  // namespace rtmi

@@ -355,3 +355,48 @@ def test_oom_and_device_error_codes():
         assert_bits_equal(ref, img, "render after the provoked errors")
     finally:
         L.rtmi_scene_destroy(h)
+
+
+def test_corners_are_optional_and_only_tighten_the_bvh():
+    """rtmi_scene_set_corners: the opt-in BVH mode gives the same hits with the disc boxes alone (no corners) and with the
+    corners' boxes -- rtmi_trace on primary + random rays, ids / times / faces bit-equal -- and equals the exact octree
+    traversal wherever neither a tie nor a lost triangle is involved (here: everywhere on this scene's primary rays).
+    Wrong sizes and NULL are RTMI_ERR_INVALID and leave the scene usable."""
+    from oracle import orc
+    from conftest import recipe_circles
+    L, ffi = _lib()
+    L.rtmi_scene_set_corners.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    so = recipe_circles()(OracleApi(orc))
+    tris, geo, topo, refs = _abi_arrays(so)
+    rec, _, _ = so.triangles()
+    corners = np.ascontiguousarray(rec[:, 20:29], np.float32)
+    rc, h = _create(L, tris, _boxes(geo, topo), refs)
+    assert rc == RTMI_OK
+    try:
+        vp12 = orc.canonical_viewport(48, 48)
+        o4, d4 = orc.primary_rays(48, 48, vp12, 1)
+        rng = np.random.default_rng(3)
+        ro = np.zeros((4000, 4), np.float32); rd = np.zeros((4000, 4), np.float32)
+        ro[:, :3] = rng.uniform(-4, 4, (4000, 3)) + np.array([0, 0, 8]); d = rng.normal(size=(4000, 3)); rd[:, :3] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        o4 = np.concatenate([o4, ro]); d4 = np.concatenate([d4, rd])
+        n = len(o4)
+
+        def trace(options):
+            L.rtmi_scene_set_options(h, options)
+            tri, t, face = np.zeros(n, np.uint32), np.zeros(n, np.float32), np.zeros(n, np.uint32)
+            assert L.rtmi_trace(h, n, o4.ctypes.data_as(C.c_void_p), d4.ctypes.data_as(C.c_void_p), tri.ctypes.data_as(C.c_void_p),
+                                t.ctypes.data_as(C.c_void_p), face.ctypes.data_as(C.c_void_p), None) == RTMI_OK, L.rtmi_last_error()
+            return tri, t, face
+        a = trace(8)                                   # RTMI_OPT_BVH, boxes from the bounding-radius discs
+        assert L.rtmi_scene_set_corners(h, corners.ctypes.data_as(C.c_void_p), len(corners) + 1) == RTMI_ERR_INVALID
+        assert L.rtmi_scene_set_corners(h, None, len(corners)) == RTMI_ERR_INVALID
+        assert L.rtmi_scene_set_corners(h, corners.ctypes.data_as(C.c_void_p), len(corners)) == RTMI_OK, L.rtmi_last_error()
+        b = trace(8)                                   # the same mode, boxes tightened by the corners
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2][a[0] != 0], b[2][b[0] != 0])
+        assert_bits_equal(a[1][a[0] != 0], b[1][b[0] != 0], "hit times, BVH with and without corners")
+        e = trace(0)                                   # exact octree traversal
+        same = e[0] == b[0]
+        assert same.mean() > 0.995, same.mean()       # ties / lost triangles aside (none expected on these rays)
+        assert_bits_equal(e[1][same & (e[0] != 0)], b[1][same & (e[0] != 0)], "hit times where the modes agree on the triangle")
+    finally:
+        L.rtmi_scene_destroy(h)
