@@ -802,6 +802,7 @@ struct rtmi_scene {
     // against setenv): waves per CU of the octree kernel, refill thresholds, XCD mode, streams, batch size
     rtmi_tuning_t tune{};
     bool verbose = false;
+    int vote[4] = {3, 2, 3, 2};  // SELECT : LEAF vote weights of the walk, primary rays / bounce rays (experiments: RTMI_VOTE="a,b,c,d")
     unsigned long long vprev[RTMI_MAX_STREAMS][13] = {};  // verbose per-pass deltas (per handle: no shared statics)
 };
 
@@ -1034,6 +1035,10 @@ int rtmi_scene_create(const rtmi_triangle_t* tris, uint64_t ntris, const rtmi_bo
     s->tune.pipeline = (uint32_t)std::min<size_t>(env_size("RTMI_PIPELINE", 0), 3);
     s->tune.slow_path_off = (uint32_t)std::min<size_t>(env_size("RTMI_SLOW_PATH_OFF", 0), 1);
     s->verbose = getenv("RTMI_VERBOSE") != nullptr;
+    if (const char* v = getenv("RTMI_VOTE")) {
+        int q[4];
+        if (sscanf(v, "%d,%d,%d,%d", &q[0], &q[1], &q[2], &q[3]) == 4 && q[0] > 0 && q[1] > 0 && q[2] > 0 && q[3] > 0) memcpy(s->vote, q, sizeof q);
+    }
     s->trace_block = block;
     s->trace_lds = (size_t)levels * 16 * block;
     hipDeviceProp_t prop;
@@ -1268,6 +1273,7 @@ static void launch_trace(rtmi_scene* s, Work& w, hipStream_t st, const float4* q
         } else {
             OctArgs a{};
             a.qo = qo; a.qd = qd; a.hit_tf = w.hit_tf.p; a.hit_t = w.hit_t.p; a.pass = pass;
+            a.vote_s = pass == 0 ? s->vote[0] : s->vote[2]; a.vote_l = pass == 0 ? s->vote[1] : s->vote[3];
             if (s->options & RTMI_OPT_FAST)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_oct<COUNT, true>), grid, block, s->oct_lds, st, s->d, a, w.ctrl.p, refill, xcd);
             else
@@ -1304,6 +1310,7 @@ static void launch_path(rtmi_scene* s, Work& w, hipStream_t st, int which, const
     a.bqo = w.qo[bq].p; a.bqd = w.qd[bq].p; a.bqpath = w.qpath[bq].p;
     a.mstack = w.mstack.p; a.scol = w.scol.p;
     a.slow = slow_queue(s, w);
+    a.vote_s = which == W_PRIMARY ? s->vote[0] : s->vote[2]; a.vote_l = which == W_PRIMARY ? s->vote[1] : s->vote[3];
     const bool fast = (s->options & RTMI_OPT_FAST) != 0;
     if (which == W_SLOW) {
         // consumer launch `queue` of the slow path, on the side stream: after the producer whose event is sev[queue]

@@ -90,6 +90,7 @@ struct OctArgs {
     uint16_t* mstack; float4* scol;
     SlowQ slow;       // W_PRIMARY: where zero-component rays go (cap == 0: nowhere, they are traced in place); W_SLOW: the queue
     uint32_t slow_k;  // W_SLOW: which consumer launch this is (its range and cursor in the control block)
+    int vote_s, vote_l;  // weights of the SELECT / LEAF vote (3 : 2)
 };
 
 // Frame of an inner box: node = index of its record; w = visited octants (bits 0-7) | O_DONE | O_HAS;
@@ -312,7 +313,7 @@ __device__ __forceinline__ void oct_walk(const DScene& sc, const OctArgs& a, DCt
         const unsigned long long t_s0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
         // Majority vote, weighted 3 : 2 towards SELECT: a LEAF step costs 1.7 x the instructions of a SELECT step, so it pays
         // to let a few more lanes gather for it (1:1 918, 3:2 925, 2:1 920, 2:3 905 Mrays/s);
-        const bool stepS = nS * 3 >= nL * 2;
+        const bool stepS = nS * a.vote_s >= nL * a.vote_l;
         if (COUNT && lane == 0) { if (stepS) { dbg[0]++; dbg[1] += nS; } else { dbg[2]++; dbg[3] += nL; } }
         if (stepS) {  // hysteresis (stay in a phase until its lanes fall below 1/2..1/8 of the other's) measured 1-7 % slower
             // ================================================= SELECT step
