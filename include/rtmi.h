@@ -239,7 +239,14 @@ int rtmi_render_tile_device(rtmi_scene_t* scene, const rtmi_viewport_t* vp, uint
  * 3 bytes per pixel cross the links instead of 16 and the output is height*width*3 bytes; otherwise the output is
  * height*width*4 floats (`[Color]`).  out_host and/or out_device (memory of scenes[0]'s device) receive the frame.
  * stats (optional) has nscenes entries, one per scene; "Rays" of the frame is their sum. */
-enum { RTMI_FRAME_RGB8 = 1u << 0 };
+enum {
+    RTMI_FRAME_RGB8 = 1u << 0,
+    RTMI_FRAME_RCCL = 1u << 1  /* the bands cross to scenes[0]'s device with ONE ncclGather (RCCL over xGMI; rccl.h) on a
+                                * communicator the library makes for the scenes' devices (ncclCommInitAll, kept on scenes[0])
+                                * instead of one hipMemcpyPeerAsync per band.  librccl.so.1 is loaded on first use (a process
+                                * that holds PyTorch's RCCL gets that copy).  Every scene handle must sit on a device of its
+                                * own.  Same frame either way; without the flag the library stays free of RCCL.            */
+};
 int rtmi_render_frame_multi(rtmi_scene_t* const* scenes, uint32_t nscenes, const rtmi_viewport_t* vp, uint64_t seed,
                             uint32_t stripe_rows, uint32_t flags, void* out_host, void* out_device, rtmi_stats_t* stats);
 

@@ -18,6 +18,8 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (strict IEEE f32:
 // correctly rounded / and sqrtf are hipcc defaults, contraction is not).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is dlopen'ed when RTMI_FRAME_RCCL is asked for
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cfloat>
@@ -28,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -792,6 +795,8 @@ struct rtmi_scene {
     DevBuf<uint8_t> qbytes;
     DevBuf<uint8_t> mstage, mframe;  // rtmi_render_frame_multi, root scene: received bands / the frame
     hipStream_t mstream = nullptr;   // rtmi_render_frame_multi: this scene's band stream
+    std::vector<ncclComm_t> comms;   // root scene, RTMI_FRAME_RCCL: one communicator per scene of the last device list
+    std::vector<int> comm_devices;
     int peer_root = -1;              // root device the peer-access state below refers to (-1: not asked yet)
     int peer_ok = 0;                 // 1 = this device reaches peer_root directly (enabled once), 0 = the runtime refused
     std::string peer_msg;            // the runtime's reason when it refused
@@ -805,6 +810,38 @@ struct rtmi_scene {
     int vote[4] = {3, 2, 3, 2};  // SELECT : LEAF vote weights of the walk, primary rays / bounce rays (experiments: RTMI_VOTE="a,b,c,d")
     unsigned long long vprev[RTMI_MAX_STREAMS][13] = {};  // verbose per-pass deltas (per handle: no shared statics)
 };
+
+// RCCL for RTMI_FRAME_RCCL, loaded on first use: no link-time dependency, and in a process that already holds PyTorch's
+// RCCL (same SONAME librccl.so.1) dlopen hands back that copy instead of mapping a second one.
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+static Rccl* rccl_api() {
+    static Rccl api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) return;
+        api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.lib, "ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+        api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
+        api.Gather = (decltype(api.Gather))dlsym(api.lib, "ncclGather");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+        api.ok = api.CommInitAll && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Gather && api.GetErrorString;
+    });
+    return api.ok ? &api : nullptr;
+}
 
 // (Re)build the fast-mode BVH (bvh_fast.hpp) from the scene's triangle records and, when given, their corners.
 static int upload_bvh(rtmi_scene* s, const float* corners9) {
@@ -1123,6 +1160,7 @@ int rtmi_scene_destroy(rtmi_scene_t* s) {
     if (s->end_ev) (void)hipEventDestroy(s->end_ev);
     s->tile.release(); s->qbytes.release(); s->mstage.release(); s->mframe.release();
     if (s->mstream) (void)hipStreamDestroy(s->mstream);
+    if (!s->comms.empty()) { if (Rccl* r = rccl_api()) for (ncclComm_t c : s->comms) (void)r->CommDestroy(c); }
     delete s;
     return RTMI_OK;
 }
@@ -1665,8 +1703,19 @@ int rtmi_render_frame_multi(rtmi_scene_t* const* scenes, uint32_t nscenes, const
     }
     if (!out_host && !out_device) return fail(RTMI_ERR_INVALID, "out_host and out_device are both NULL");
     if (vp->width == 0 || vp->height == 0) return fail(RTMI_ERR_INVALID, "empty viewport");
-    if (flags & ~(uint32_t)RTMI_FRAME_RGB8) return fail(RTMI_ERR_INVALID, "unknown flag");
+    if (flags & ~(uint32_t)(RTMI_FRAME_RGB8 | RTMI_FRAME_RCCL)) return fail(RTMI_ERR_INVALID, "unknown flag");
     RTMI_GUARD_BEGIN
+    const bool use_rccl = (flags & RTMI_FRAME_RCCL) != 0;
+    Rccl* rccl = nullptr;
+    if (use_rccl) {
+        // one communicator rank per scene handle: RCCL wants every rank on a device of its own
+        for (uint32_t i = 0; i < nscenes; i++)
+            for (uint32_t j = 0; j < i; j++)
+                if (scenes[j]->device == scenes[i]->device)
+                    return fail(RTMI_ERR_UNSUPPORTED, "RTMI_FRAME_RCCL needs every scene handle on a device of its own (RCCL refuses two ranks on one GPU)");
+        rccl = rccl_api();
+        if (!rccl) return fail(RTMI_ERR_UNSUPPORTED, "RTMI_FRAME_RCCL: librccl.so.1 could not be loaded");
+    }
     const uint32_t W = vp->width, H = vp->height, n = nscenes;
     const uint32_t S = stripe_rows ? stripe_rows : 16u;
     const bool rgb8 = (flags & RTMI_FRAME_RGB8) != 0;
@@ -1696,8 +1745,9 @@ int rtmi_render_frame_multi(rtmi_scene_t* const* scenes, uint32_t nscenes, const
         const int peer = sc->peer_ok;
         if (rows[i] == 0) { st.peer_access = peer; return; }
         if (e == hipSuccess && !sc->mstream) e = hipStreamCreateWithFlags(&sc->mstream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = sc->tile.ensure((size_t)rows[i] * W);
-        if (e == hipSuccess && rgb8) e = sc->qbytes.ensure((size_t)rows[i] * W * 3);
+        // (a gather sends the same count from every rank: the band buffers then hold the padded band of `mr` rows)
+        if (e == hipSuccess) e = sc->tile.ensure((size_t)(use_rccl ? mr : rows[i]) * W);
+        if (e == hipSuccess && rgb8) e = sc->qbytes.ensure((size_t)(use_rccl ? mr : rows[i]) * W * 3);
         if (e != hipSuccess) return bail(hip_code(e), std::string("rtmi_render_frame_multi: ") + hipGetErrorString(e));
         const rtmi_tile_t tile{i * S, rows[i], S, n * S};
         const clk::time_point t0 = clk::now();
@@ -1711,6 +1761,11 @@ int rtmi_render_frame_multi(rtmi_scene_t* const* scenes, uint32_t nscenes, const
             hipLaunchKernelGGL(k_quantize, dim3((unsigned)(sc->num_cu * 8)), dim3(256), 0, sc->mstream, (uint64_t)rows[i] * W,
                                (const float4*)sc->tile.p, sc->qbytes.p);
             band = sc->qbytes.p;
+        }
+        if (use_rccl) {  // the bands cross together below, in ONE ncclGather; here only the quantisation is awaited
+            e = hipStreamSynchronize(sc->mstream);
+            if (e != hipSuccess) return bail(hip_code(e), std::string("rtmi_render_frame_multi: ") + hipGetErrorString(e));
+            return;
         }
         // the single crossing of this band: its own link to the root (a plain device copy when both are one device)
         e = hipMemcpyPeerAsync(root->mstage.p + (size_t)i * mr * W * px, root->device, band, sc->device, (size_t)rows[i] * W * px, sc->mstream);
@@ -1740,6 +1795,40 @@ int rtmi_render_frame_multi(rtmi_scene_t* const* scenes, uint32_t nscenes, const
         if (!scenes[i]->peer_ok && warn.empty())
             warn = "warning: device " + std::to_string(scenes[i]->device) + " has no peer access to root device " + std::to_string(root->device) +
                    " (" + scenes[i]->peer_msg + "): its band is staged by the runtime, see rtmi_stats_t.peer_access / band_copy_ms";
+    }
+    if (use_rccl) {
+        // ---- ONE ncclGather over the scenes' devices (rccl.h ncclGather): every rank sends its padded band, the
+        //      root receives them rank-major into the staging buffer the de-interleave kernel reads.  Communicators are
+        //      made once per device list (ncclCommInitAll) and kept on the root handle.
+        std::vector<int> devs(n);
+        for (uint32_t i = 0; i < n; i++) devs[i] = scenes[i]->device;
+        if (root->comm_devices != devs) {
+            for (ncclComm_t c : root->comms) (void)rccl->CommDestroy(c);
+            root->comms.assign(n, nullptr);
+            root->comm_devices.clear();
+            const ncclResult_t r = rccl->CommInitAll(root->comms.data(), (int)n, devs.data());
+            if (r != ncclSuccess) { root->comms.clear(); return fail(RTMI_ERR_DEVICE, std::string("ncclCommInitAll: ") + rccl->GetErrorString(r)); }
+            root->comm_devices = devs;
+        }
+        const clk::time_point t1 = clk::now();
+        const size_t count = (size_t)mr * W * px;  // bytes per rank
+        ncclResult_t r = rccl->GroupStart();
+        for (uint32_t i = 0; i < n && r == ncclSuccess; i++) {
+            rtmi_scene* sc = scenes[i];
+            HIPCHK(hipSetDevice(sc->device));
+            if (!sc->mstream) HIPCHK(hipStreamCreateWithFlags(&sc->mstream, hipStreamNonBlocking));
+            if (rows[i] == 0) { HIPCHK(sc->tile.ensure((size_t)mr * W)); if (rgb8) HIPCHK(sc->qbytes.ensure((size_t)mr * W * 3)); }
+            const void* band = rgb8 ? (const void*)sc->qbytes.p : (const void*)sc->tile.p;
+            r = rccl->Gather(band, i == 0 ? (void*)root->mstage.p : nullptr, count, ncclUint8, 0, root->comms[i], sc->mstream);
+        }
+        const ncclResult_t r2 = rccl->GroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) return fail(RTMI_ERR_DEVICE, std::string("ncclGather: ") + rccl->GetErrorString(r));
+        for (uint32_t i = 0; i < n; i++) {
+            HIPCHK(hipSetDevice(scenes[i]->device));
+            HIPCHK(hipStreamSynchronize(scenes[i]->mstream));
+            sts[i].band_copy_ms = ms_since(t1);
+        }
     }
     // ---- root: de-interleave the stripes into the frame
     HIPCHK(hipSetDevice(root->device));

@@ -260,10 +260,11 @@ class HipRayCaster:
                 print(f"rows {r0}..{r1 - 1} done: {ctx.stats_line()}", flush=True)
         return ProgressCtx(total, secs, summed)
 
-    def walk_frame_multi(self, v, s, data=None, rgb8=False, stripe_rows=0, out_device_ptr=None):
+    def walk_frame_multi(self, v, s, data=None, rgb8=False, stripe_rows=0, out_device_ptr=None, rccl=False):
         """One frame striped over self.devices inside the library.  data: (H, W, 4) f32, or (H, W, 3) u8 with rgb8=True
-        (each band is quantised on its device before it crosses to the root).  Returns ProgressCtx; .per_device holds the
-        stats of every device."""
+        (each band is quantised on its device before it crosses to the root).  rccl=True: the bands cross with one ncclGather
+        (RTMI_FRAME_RCCL; every entry of self.devices must then be a different device).  Returns ProgressCtx; .per_device
+        holds the stats of every device."""
         want = (np.uint8, 3) if rgb8 else (np.float32, 4)
         if data is not None and (data.dtype != want[0] or not data.flags.c_contiguous or data.size != v.height * v.width * want[1]):
             raise ValueError("data must be C-contiguous (H, W, 4) float32, or (H, W, 3) uint8 with rgb8")
@@ -273,7 +274,7 @@ class HipRayCaster:
         per = (_ffi.Stats * n)()
         wall = C.c_double(0)
         _chk(_ffi.lib().rth_caster_walk_frame_multi(s.h, v.width, v.height, _p(v.vp12), v.maxdepth, v.samples_per_pixel, stripe_rows,
-                                                    1 if rgb8 else 0, _p(data) if data is not None else None,
+                                                    (1 if rgb8 else 0) | (2 if rccl else 0), _p(data) if data is not None else None,
                                                     C.c_void_p(out_device_ptr or 0), C.byref(st), per, n, C.byref(wall)))
         ctx = ProgressCtx(st.rays, wall.value, st.as_dict())
         ctx.per_device = [p.as_dict() for p in per]

@@ -279,6 +279,27 @@ def test_render_frame_multi_raw_abi():
         rc = L.rtmi_render_frame_multi(arr, n, C.byref(vp), seed, S, 1, q.ctypes.data_as(C.c_void_p), None, None)
         assert rc == RTMI_OK, L.rtmi_last_error()
         assert np.array_equal(q.reshape(-1, 3), orc.quantize(ref)), f"rgb8 n={n} S={S}"
+    # RTMI_FRAME_RCCL (flag 2): the bands cross with ONE ncclGather on a communicator of the scenes' devices.  This box has
+    # one GPU: one handle runs the whole path (librccl loaded on first use, ncclCommInitAll, grouped ncclGather into the
+    # staging buffer, de-interleave) twice (the communicator is kept), f32 and RGB8; two handles on ONE device are refused
+    # (RCCL wants a device per rank) without disturbing the handles.  Untested here: more than one physical device.
+    arr = (C.c_void_p * 1)(hs[0].value)
+    for _ in range(2):
+        out = np.zeros((hgt, w, 4), np.float32)
+        sts = (ffi.Stats * 1)()
+        rc = L.rtmi_render_frame_multi(arr, 1, C.byref(vp), seed, 4, 2, out.ctypes.data_as(C.c_void_p), None, sts)
+        assert rc == RTMI_OK, L.rtmi_last_error()
+        assert_bits_equal(whole, out, "one handle, ncclGather")
+        assert sts[0].rays == cn["rays"] and sts[0].band_copy_ms > 0
+    q = np.zeros((hgt, w, 3), np.uint8)
+    assert L.rtmi_render_frame_multi(arr, 1, C.byref(vp), seed, 4, 2 | 1, q.ctypes.data_as(C.c_void_p), None, None) == RTMI_OK, L.rtmi_last_error()
+    assert np.array_equal(q.reshape(-1, 3), orc.quantize(ref)), "rgb8 through ncclGather"
+    arr = (C.c_void_p * 2)(hs[0].value, hs[1].value)
+    out = np.zeros((hgt, w, 4), np.float32)
+    assert L.rtmi_render_frame_multi(arr, 2, C.byref(vp), seed, 4, 2, out.ctypes.data_as(C.c_void_p), None, None) == RTMI_ERR_UNSUPPORTED
+    assert b"device of its own" in L.rtmi_last_error()
+    assert L.rtmi_render_frame_multi(arr, 2, C.byref(vp), seed, 4, 0, out.ctypes.data_as(C.c_void_p), None, None) == RTMI_OK
+    assert_bits_equal(whole, out, "peer copies again after the refused RCCL call")
     # errors: the same handle twice, no output, unknown flag
     arr = (C.c_void_p * 2)(hs[0].value, hs[0].value)
     out = np.zeros((hgt, w, 4), np.float32)
